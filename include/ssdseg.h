@@ -1,0 +1,261 @@
+/*
+ * ssdseg.h -- C-ABI of libssdseg_hip.so: the MI355X (gfx950) hot path of `ssdseglib`.
+ *
+ * The reference (matteo-stat/multi-task-learning-object-detection-semantic-segmentation) is pure Python on
+ * TensorFlow/Keras: it has no FFI of its own.  The boundary replaced here is therefore the set of TensorFlow
+ * ops its hot path invokes; every entry point below cites the reference call
+ * sites (file:line under the reference root) whose arithmetic it replaces.  The Python host
+ * (`ssdseglib/_hip.py`, ctypes) is the only caller; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes only, no C++/torch types.  All tensors are dense fp32, NHWC for activations,
+ *     HWIO ([kh][kw][cin][cout]) for dense conv kernels, [kh][kw][c] for depthwise kernels, [cin][cout] for
+ *     pointwise kernels (== Keras layouts, so get_weights()/set_weights() are memcpy).
+ *   - every pointer is a DEVICE pointer unless the parameter name ends in `_host`.
+ *   - every function returns 0 on success, -(hipError_t) for a HIP failure, or SSDSEG_EINVAL (-1000-n) for
+ *     argument n being invalid.  Nothing throws across the boundary.  `ssdseg_last_error()` returns a
+ *     thread-local description of the last failure.
+ *   - launches are asynchronous on the ctx stream; `ssdseg_ctx_sync` waits.  A ctx is single-threaded.
+ *   - kernels never allocate.  Scratch (BN partial sums, weight-gradient partial slabs, top-k histograms) comes
+ *     from a ctx-owned workspace that grows on demand *outside* of launches (ssdseg_ctx_reserve).
+ *
+ * "Activation view" -- how conv + BatchNorm(train) + ReLU6 are fused:
+ *   a conv kernel writes its RAW output y and per-block partial (sum, sum-of-squares) per channel; a tiny
+ *   finalize kernel turns those into per-channel (scale, shift) = (gamma*invstd, beta - mean*gamma*invstd);
+ *   every CONSUMER applies a = act(scale*y + shift) while loading.  So each activation is written once (raw)
+ *   and never re-written normalised.  `ssdseg_view` describes such an input.
+ *
+ * "Gradient view" -- BatchNorm backward folded into the consumer of dY:
+ *   given g = dL/d(act output), raw y and per-channel coefficients, the conv backward kernels form
+ *       dy = scale * mask(z) * g + k1 * y + k0,   z = scale*y + shift,  mask = act'(z)
+ *   on load (k1, k0 come from ssdseg_bn_bwd_finalize).  With scale == NULL the view is the identity (dy = g).
+ */
+#ifndef SSDSEG_H
+#define SSDSEG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSDSEG_VERSION 1
+#define SSDSEG_EINVAL(n) (-1000 - (n))
+
+/* activation applied by a view (Keras ReLU(max_value=...) semantics) */
+enum {
+    SSDSEG_ACT_NONE = 0,  /* linear (MobileNetV2 project BN: models.py:110-111)                     */
+    SSDSEG_ACT_RELU = 1,  /* tf.nn.relu, grad iff z > 0 (ShuffleNetV2 backbone: models.py:529,540)    */
+    SSDSEG_ACT_RELU6 = 2, /* tf.nn.relu6, grad iff 0 < z < 6 (models.py:67,90; blocks.py:30,...)      */
+    SSDSEG_ACT_ZERO = 3   /* ReLU(max_value=0.0): output 0, grad 0 (quirk Q1: blocks.py:4,76,134)     */
+};
+
+typedef struct ssdseg_ctx ssdseg_ctx;
+
+/* input view: a = act(scale[c] * x + shift[c]); scale == NULL -> a = act(x) */
+typedef struct {
+    const float* x;
+    const float* scale;
+    const float* shift;
+    int32_t act;
+    int32_t _pad;
+} ssdseg_view;
+
+/* gradient view: dy = scale[c]*mask(scale[c]*y+shift[c])*g + k1[c]*y + k0[c]; scale == NULL -> dy = g */
+typedef struct {
+    const float* g;
+    const float* y;
+    const float* scale;
+    const float* shift;
+    const float* k1;
+    const float* k0;
+    int32_t act;
+    int32_t _pad;
+} ssdseg_gview;
+
+/* ---------------------------------------------------------------- context, memory, timing */
+const char* ssdseg_last_error(void);
+int ssdseg_version(void);
+int ssdseg_device_count(int* count_host);
+/* stream == NULL: the ctx creates (and owns) a non-blocking stream; otherwise it borrows the caller's
+ * hipStream_t (e.g. torch.cuda.current_stream().cuda_stream when RCCL plumbing is torch.distributed). */
+int ssdseg_ctx_create(int device, void* stream, ssdseg_ctx** out_host);
+int ssdseg_ctx_destroy(ssdseg_ctx* ctx);
+int ssdseg_ctx_sync(ssdseg_ctx* ctx);
+int ssdseg_ctx_reserve(ssdseg_ctx* ctx, size_t workspace_bytes);
+int ssdseg_ctx_device_name(ssdseg_ctx* ctx, char* buf_host, size_t buf_len);
+int ssdseg_malloc(ssdseg_ctx* ctx, size_t bytes, void** out_host);
+int ssdseg_free(ssdseg_ctx* ctx, void* ptr);
+int ssdseg_memcpy_h2d(ssdseg_ctx* ctx, void* dst, const void* src_host, size_t bytes);
+int ssdseg_memcpy_d2h(ssdseg_ctx* ctx, void* dst_host, const void* src, size_t bytes);
+int ssdseg_memcpy_d2d(ssdseg_ctx* ctx, void* dst, const void* src, size_t bytes);
+int ssdseg_memset(ssdseg_ctx* ctx, void* dst, int value, size_t bytes);
+/* HIP events on the ctx stream (bench.py times kernels with these, not with torch events) */
+int ssdseg_event_create(ssdseg_ctx* ctx, void** out_host);
+int ssdseg_event_destroy(ssdseg_ctx* ctx, void* ev);
+int ssdseg_event_record(ssdseg_ctx* ctx, void* ev);
+int ssdseg_event_elapsed_ms(ssdseg_ctx* ctx, void* ev_start, void* ev_stop, float* ms_host);
+/* hipGraph capture of a sequence of launches on the ctx stream (launch-bound inner loops) */
+int ssdseg_graph_begin(ssdseg_ctx* ctx);
+int ssdseg_graph_end(ssdseg_ctx* ctx, void** graph_exec_host);
+int ssdseg_graph_launch(ssdseg_ctx* ctx, void* graph_exec);
+int ssdseg_graph_destroy(ssdseg_ctx* ctx, void* graph_exec);
+
+/* ---------------------------------------------------------------- K1+K2: stem conv
+ * Conv2D 3x3 stride 2 SAME on the rescaled image, tiny Cin (models.py:187 Rescaling x/127.5-1, :196 -> :65;
+ * ShuffleNetV2 stem models.py:622,628 with bias).  in = x*in_scale + in_offset fused into the load.
+ * y: [n][ho][wo][cout] raw.  stats: [nparts][2][cout] partial (sum, sumsq), may be NULL.
+ * ssdseg_stem_conv_parts() tells how many partial rows the launch writes. */
+int ssdseg_stem_conv_parts(int n, int h, int w, int cout, int* nparts_host);
+int ssdseg_stem_conv_fwd(ssdseg_ctx* ctx, const float* x, const float* w, const float* bias, float* y,
+                         int n, int h, int wdt, int cin, int cout, float in_scale, float in_offset,
+                         float* stats);
+/* dW (and dbias) only: the image needs no gradient.  dw: [3][3][cin][cout]. */
+int ssdseg_stem_conv_bwd_weight(ssdseg_ctx* ctx, const float* x, const ssdseg_gview* dy, float* dw,
+                                float* dbias, int n, int h, int wdt, int cin, int cout, float in_scale,
+                                float in_offset);
+
+/* ---------------------------------------------------------------- K3+K4: depthwise 3x3 (stride 1|2, dilation >= 1)
+ * DepthwiseConv2D / depthwise half of SeparableConv2D, SAME padding, depth multiplier 1
+ * (models.py:88,236,242,524,533,542,577,586; blocks.py:33,38,43,122,152).
+ * TF SAME: out = ceil(in/s), pad_total = max((out-1)*s + (k-1)*d + 1 - in, 0), before = pad_total/2. */
+int ssdseg_dwconv_parts(int n, int h, int w, int c, int stride, int* nparts_host);
+int ssdseg_dwconv_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, float* y, int n, int h, int wdt,
+                      int c, int stride, int dilation, float* stats);
+/* dx (= dL/d(act output of the producer), same shape as the input) and dw [3][3][c] in one pass.
+ * accumulate != 0: dx += result (fan-out taps).  dx may be NULL (only dw wanted). */
+int ssdseg_dwconv_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, const ssdseg_gview* dy, float* dx,
+                      float* dw, int n, int h, int wdt, int c, int stride, int dilation, int accumulate);
+
+/* ---------------------------------------------------------------- K5: pointwise 1x1 conv == GEMM [m,k] x [k,n]
+ * Conv2D 1x1 / pointwise half of SeparableConv2D (models.py:65,110,527,...; blocks.py:28,58,70,109).
+ * fp32-input MFMA (v_mfma_f32_32x32x2_f32): exact fp32 products, fp32 accumulate.
+ * ldx/ldy: row strides in floats (>= k / >= n) so a layer can read/write a channel slice of a concat buffer
+ * (K10: Concatenate is a write offset, never a copy). */
+int ssdseg_pwconv_parts(int m, int n, int* nparts_host);
+int ssdseg_pwconv_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const float* w, float* y, int ldy, int m,
+                      int k, int n, float* stats);
+/* dx[m][k] = dy[m][n] * w^T; residual != NULL: dx += residual (Add backward, models.py:162);
+ * accumulate != 0: dx += previous contents. */
+int ssdseg_pwconv_bwd_data(ssdseg_ctx* ctx, const ssdseg_gview* dy, int ldy, const float* w, float* dx, int ldx,
+                           int m, int k, int n, const float* residual, int ldr, int accumulate);
+/* dw[k][n] = sum_m in[m][k] * dy[m][n] */
+int ssdseg_pwconv_bwd_weight(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssdseg_gview* dy, int ldy,
+                             float* dw, int m, int k, int n);
+
+/* ---------------------------------------------------------------- K6: dense 3x3 stride 1 SAME (implicit GEMM)
+ * Conv2D 3x3 in the DeepLabV3+ decoder (blocks.py:117,127).  w: [3][3][cin][cout]. */
+int ssdseg_conv3x3_parts(int n, int h, int w, int cout, int* nparts_host);
+int ssdseg_conv3x3_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const float* w, float* y, int n, int h,
+                       int wdt, int cin, int cout, float* stats);
+int ssdseg_conv3x3_bwd_data(ssdseg_ctx* ctx, const ssdseg_gview* dy, const float* w, float* dx, int ldx, int n,
+                            int h, int wdt, int cin, int cout, int accumulate);
+int ssdseg_conv3x3_bwd_weight(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssdseg_gview* dy, float* dw,
+                              int n, int h, int wdt, int cin, int cout);
+
+/* ---------------------------------------------------------------- K7/K8: BatchNormalization (training) + activation
+ * Keras BatchNormalization defaults eps 1e-3, momentum 0.99 (models.py:66,89,111,...; blocks.py:29,...).
+ * finalize: partial (sum, sumsq)[nparts][2][c] over `count` samples per channel ->
+ *   mean, biased var -> scale = gamma*rsqrt(var+eps), shift = beta - mean*scale, invstd;
+ *   moving_mean <- mom*mm + (1-mom)*mean; moving_var <- mom*mv + (1-mom)*var*count/(count-1) (Bessel, App. B.3).
+ * training == 0: scale/shift from the moving statistics (inference), partials ignored. */
+int ssdseg_bn_finalize(ssdseg_ctx* ctx, const float* stats, int nparts, int c, double count, const float* gamma,
+                       const float* beta, float eps, float momentum, float* moving_mean, float* moving_var,
+                       float* mean, float* invstd, float* scale, float* shift, int training);
+/* plain per-channel (sum, sumsq) of a tensor [m][c] (row stride ld) -> stats[nparts][2][c] (for tensors
+ * not produced by one of the conv kernels, e.g. the GAP branch) */
+int ssdseg_channel_stats_parts(int m, int c, int* nparts_host);
+int ssdseg_channel_stats(ssdseg_ctx* ctx, const float* x, int ld, int m, int c, float* stats);
+/* materialise out = act(scale*x + shift) (+ residual): Add (models.py:162,593), taps, concat slices */
+int ssdseg_bn_apply(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const float* residual, int ldr, float* out,
+                    int ldo, int m, int c);
+/* BN backward reductions: dbeta = sum mask*g, dgamma = sum mask*g*xhat over [m][c]; writes
+ * dgamma, dbeta (added into the trainable-gradient buffers) and the gview coefficients k1, k0. */
+int ssdseg_bn_bwd_reduce(ssdseg_ctx* ctx, const float* g, int ldg, const float* y, int ldy, int m, int c,
+                         const float* scale, const float* shift, const float* mean, const float* invstd, int act,
+                         float* dgamma, float* dbeta, float* k1, float* k0);
+/* dst (+)= src over [m][c] with row strides (gradient fan-in: Concatenate / Add backward) */
+int ssdseg_axpby(ssdseg_ctx* ctx, const float* src, int lds, float* dst, int ldd, int m, int c, float a, float b);
+
+/* ---------------------------------------------------------------- K11: GlobalAveragePooling2D keepdims (blocks.py:57) */
+int ssdseg_gap_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, float* out, int n, int hw, int c);
+/* dx[n][hw][c] (+)= g[n][c] / hw */
+int ssdseg_gap_bwd(ssdseg_ctx* ctx, const float* g, float* dx, int n, int hw, int c, int accumulate);
+
+/* ---------------------------------------------------------------- K12: UpSampling2D bilinear, half-pixel (blocks.py:61,104,129)
+ * out[n][h*fy][w*fx][c] written with row stride ldo (concat slice). */
+int ssdseg_bilinear_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, float* out, int ldo, int n, int h, int wdt,
+                        int c, int fy, int fx);
+int ssdseg_bilinear_bwd(ssdseg_ctx* ctx, const float* g, int ldg, float* dx, int ldx, int n, int h, int wdt, int c,
+                        int fy, int fx, int accumulate);
+
+/* ---------------------------------------------------------------- K12+K13: mask head tail
+ * logits [n][h][w][c] --x(fy,fx) bilinear--> softmax -> probabilities (output-mask, blocks.py:128-130),
+ * optionally fused with the weighted cross-entropy (losses.py:294-303): loss[n] = -sum_c w_c sum_px y*log(clip p).
+ * prob may be NULL (training does not need it stored); y_true/loss may be NULL (inference). */
+int ssdseg_mask_head_fwd(ssdseg_ctx* ctx, const float* logits, int n, int h, int wdt, int c, int fy, int fx,
+                         const float* y_true, const float* class_weights, float* prob, float* loss);
+/* dlogits (low resolution) = upsample^T( softmax'( dL/dp ) ), dL/dp = -loss_scale * w_c * y / p inside the clip */
+int ssdseg_mask_head_bwd(ssdseg_ctx* ctx, const float* logits, int n, int h, int wdt, int c, int fy, int fx,
+                         const float* y_true, const float* class_weights, float loss_scale, float* dlogits);
+
+/* ---------------------------------------------------------------- K13..K15: detection losses
+ * softmax over the class axis of head logits (models.py:259) */
+int ssdseg_softmax_rows(ssdseg_ctx* ctx, const ssdseg_view* in, float* out, int rows, int c);
+/* confidence_loss (losses.py:52-172) + localization_loss (losses.py:5-49) forward and gradient in one call.
+ * y_labels/p_labels: [b][a][c] (p = probabilities); y_boxes/p_boxes: [b][a][4].
+ * conf_loss/loc_loss: [b].  d_logits: dL/d(pre-softmax logits) [b][a][c], d_boxes: dL/d p_boxes, both already
+ * scaled by loss_scale (= loss_weight / batch for Keras' SUM_OVER_BATCH_SIZE).  Either may be NULL.
+ * keep_mask (optional, uint8 [b*a]) receives the hard-negative selection (1 = kept background anchor). */
+int ssdseg_det_loss(ssdseg_ctx* ctx, const float* y_labels, const float* p_labels, const float* y_boxes,
+                    const float* p_boxes, int b, int a, int c, float loss_scale, float* conf_loss, float* loc_loss,
+                    float* d_logits, float* d_boxes, uint8_t* keep_mask);
+/* exact top-k selection used by the mining step (tf.math.top_k semantics: larger value first, lower index
+ * first among equals, losses.py:131): mask[i] = 1 for the k selected entries of values[n]. */
+int ssdseg_topk_mask(ssdseg_ctx* ctx, const float* values, int n, int k, uint8_t* mask);
+/* dice / dice_square (losses.py:175-264), API surface only: loss[n] from y_true, p [n][hw][c] */
+int ssdseg_dice_loss(ssdseg_ctx* ctx, const float* y_true, const float* p, int n, int hw, int c,
+                     const float* class_weights, int squared, float* loss);
+
+/* ---------------------------------------------------------------- K16: anchor matching + offset encoding
+ * DataEncoderDecoder._encode_ground_truth_labels_boxes (datacoder.py:205-300).
+ * anchors_corners [a][4] (xmin,ymin,xmax,ymax); gt [b][gmax][5] (label,xmin,ymin,xmax,ymax), gt_count [b].
+ * labels [b][a][c] one-hot, boxes [b][a][4] offsets; match (optional) [b][a] int32 matched gt index or -1. */
+int ssdseg_encode_targets(ssdseg_ctx* ctx, const float* anchors_corners, int a, const float* gt,
+                          const int32_t* gt_count, int b, int gmax, int c, float iou_threshold, const float* stds4_host,
+                          float* labels, float* boxes, int32_t* match);
+
+/* ---------------------------------------------------------------- K17..K19: inference tail
+ * DecodeBoxesCentroidsOffsets.call (layers.py:58-79): offsets [b][a][4] -> corners (ymin,xmin,ymax,xmax) */
+int ssdseg_decode_boxes(ssdseg_ctx* ctx, const float* offsets, const float* anchors_centroids, int b, int a,
+                        const float* stds4_host, float* corners);
+/* NonMaximumSuppression.call (layers.py:141-162) == tf.image.combined_non_max_suppression semantics
+ * (App. B.9) + repack: out [b][max_total][6] = (label, prob, xmin, ymin, xmax, ymax), zero padded;
+ * valid [b] = number of real detections. */
+int ssdseg_combined_nms(ssdseg_ctx* ctx, const float* corners, const float* probs, int b, int a, int c,
+                        int max_per_class, int max_total, float iou_threshold, float score_threshold, float* out,
+                        int32_t* valid);
+/* SegmentationSuppression.call (layers.py:203-210): class-present flags over the WHOLE batch (quirk Q6) */
+int ssdseg_seg_suppress(ssdseg_ctx* ctx, const float* mask_prob, int n_pixels_total, int c, const float* probs,
+                        int rows, float* probs_out);
+
+/* ---------------------------------------------------------------- K20: Adam (Keras 2.13, NB03#cell14)
+ * m += (g-m)(1-b1); v += (g^2-v)(1-b2); p -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps), one flat bucket.
+ * grad_scale multiplies g first (1/world_size after the RCCL sum). */
+int ssdseg_adam_step(ssdseg_ctx* ctx, float* params, const float* grads, float* m, float* v, size_t count,
+                     float lr, float beta1, float beta2, float eps, int step, float grad_scale);
+
+/* ---------------------------------------------------------------- K21: ShuffleNetV2-only ops
+ * MaxPooling2D 3x3 stride 2 SAME (models.py:629); argmax-free backward (recomputes the window max). */
+int ssdseg_maxpool3x3s2_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, float* out, int n, int h, int wdt, int c);
+int ssdseg_maxpool3x3s2_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, const float* g, float* dx, int n, int h, int wdt,
+                            int c);
+/* channel shuffle (groups) of a concat of two halves: out[.., j*g + i] = in[.., i*(c/g) + j]  (models.py:497-503) */
+int ssdseg_channel_shuffle(ssdseg_ctx* ctx, const float* in, int ldi, float* out, int ldo, int m, int c, int groups,
+                           int inverse);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSDSEG_H */

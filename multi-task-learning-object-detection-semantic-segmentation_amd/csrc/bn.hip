@@ -1,0 +1,324 @@
+// BatchNormalization (training mode) pieces that are not fused into a conv kernel, plus small elementwise helpers.
+// Keras BatchNormalization: axis -1, eps 1e-3, momentum 0.99 (reference models.py:66,89,111; blocks.py:29,...;
+// semantics SURVEY.md App. B.3).  All reductions are two-level with a fixed summation order (deterministic).
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_PARTS = 1024;
+
+// ---- [nparts][len] -> [nslots][len], slot s sums rows s*chunk .. (s+1)*chunk-1 (fixed order)
+__global__ void fold_parts_kernel(const float* __restrict__ part, int nparts, int len, int chunk, float* __restrict__ out) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= len) return;
+    const int s = blockIdx.y;
+    int p0 = s * chunk, p1 = p0 + chunk;
+    if (p1 > nparts) p1 = nparts;
+    float acc = 0.f;
+    for (int p = p0; p < p1; ++p) acc += part[(long long)p * len + l];
+    out[(long long)s * len + l] = acc;
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, int nparts, int c, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, float momentum, float* __restrict__ moving_mean,
+                                   float* __restrict__ moving_var, float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                   float* __restrict__ scale, float* __restrict__ shift, int training) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double mean, var;
+    if (training) {
+        double s = 0.0, q = 0.0;
+        for (int p = 0; p < nparts; ++p) {
+            s += (double)stats[((long long)p * 2 + 0) * c + ch];
+            q += (double)stats[((long long)p * 2 + 1) * c + ch];
+        }
+        mean = s / count;
+        var = q / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        if (moving_mean != nullptr) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            moving_mean[ch] = (float)((double)moving_mean[ch] * momentum + mean * (1.0 - (double)momentum));
+            moving_var[ch] = (float)((double)moving_var[ch] * momentum + unbiased * (1.0 - (double)momentum));
+        }
+    } else {
+        mean = (double)moving_mean[ch];
+        var = (double)moving_var[ch];
+    }
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const float sc = (float)((double)gamma[ch] * invstd);
+    const float mf = (float)mean;
+    if (mean_out) mean_out[ch] = mf;
+    if (invstd_out) invstd_out[ch] = (float)invstd;
+    scale[ch] = sc;
+    shift[ch] = (float)((double)beta[ch] - mean * (double)gamma[ch] * invstd);
+}
+
+struct RowGeom {
+    long long m;
+    int c, cv;
+};
+
+__device__ __forceinline__ void add4(float4& a, float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+
+__device__ __forceinline__ float4 reduce_over_y(float4 v, float4* red) {
+    __syncthreads();
+    red[threadIdx.y * blockDim.x + threadIdx.x] = v;
+    __syncthreads();
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (threadIdx.y == 0)
+        for (int y = 0; y < (int)blockDim.y; ++y) add4(r, red[y * blockDim.x + threadIdx.x]);
+    return r;
+}
+
+// per-channel (sum, sumsq) of x[m][c]
+__global__ void __launch_bounds__(512) channel_stats_kernel(const float* __restrict__ x, int ld, RowGeom g, float* __restrict__ stats) {
+    extern __shared__ float4 red[];
+    const int cvi = blockIdx.y * blockDim.x + threadIdx.x;
+    const bool active = cvi < g.cv;
+    float4 s = f4(0.f), q = f4(0.f);
+    if (active) {
+        for (long long r = (long long)blockIdx.x * blockDim.y + threadIdx.y; r < g.m; r += (long long)gridDim.x * blockDim.y) {
+            const float4 v = ld4(x + r * ld + cvi * 4);
+            add4(s, v);
+            q.x = fmaf(v.x, v.x, q.x); q.y = fmaf(v.y, v.y, q.y); q.z = fmaf(v.z, v.z, q.z); q.w = fmaf(v.w, v.w, q.w);
+        }
+    }
+    float4 a = reduce_over_y(s, red);
+    float4 b = reduce_over_y(q, red);
+    if (threadIdx.y == 0 && active) {
+        float* row = stats + (long long)blockIdx.x * 2 * g.c;
+        st4(row + cvi * 4, a);
+        st4(row + g.c + cvi * 4, b);
+    }
+}
+
+// partial (sum mask*g, sum mask*g*xhat) per channel
+__global__ void __launch_bounds__(512) bn_bwd_partial_kernel(const float* __restrict__ gg, int ldg, const float* __restrict__ y, int ldy,
+                                                             RowGeom g, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd, int act,
+                                                             float* __restrict__ part) {
+    extern __shared__ float4 red[];
+    const int cvi = blockIdx.y * blockDim.x + threadIdx.x;
+    const bool active = cvi < g.cv;
+    float4 sb = f4(0.f), sg = f4(0.f);
+    if (active) {
+        const float4 sc = ld4(scale + cvi * 4), sh = ld4(shift + cvi * 4), mu = ld4(mean + cvi * 4), is = ld4(invstd + cvi * 4);
+        for (long long r = (long long)blockIdx.x * blockDim.y + threadIdx.y; r < g.m; r += (long long)gridDim.x * blockDim.y) {
+            const float4 gv = ld4(gg + r * ldg + cvi * 4);
+            const float4 yv = ld4(y + r * ldy + cvi * 4);
+            float4 mg;
+            mg.x = gv.x * act_mask(fmaf(sc.x, yv.x, sh.x), act);
+            mg.y = gv.y * act_mask(fmaf(sc.y, yv.y, sh.y), act);
+            mg.z = gv.z * act_mask(fmaf(sc.z, yv.z, sh.z), act);
+            mg.w = gv.w * act_mask(fmaf(sc.w, yv.w, sh.w), act);
+            add4(sb, mg);
+            sg.x = fmaf(mg.x, (yv.x - mu.x) * is.x, sg.x);
+            sg.y = fmaf(mg.y, (yv.y - mu.y) * is.y, sg.y);
+            sg.z = fmaf(mg.z, (yv.z - mu.z) * is.z, sg.z);
+            sg.w = fmaf(mg.w, (yv.w - mu.w) * is.w, sg.w);
+        }
+    }
+    float4 a = reduce_over_y(sb, red);
+    float4 b = reduce_over_y(sg, red);
+    if (threadIdx.y == 0 && active) {
+        float* row = part + (long long)blockIdx.x * 2 * g.c;
+        st4(row + cvi * 4, a);
+        st4(row + g.c + cvi * 4, b);
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int c, double count, const float* __restrict__ scale,
+                                       const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ k1, float* __restrict__ k0) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double db = 0.0, dg = 0.0;
+    for (int p = 0; p < nparts; ++p) {
+        db += (double)part[((long long)p * 2 + 0) * c + ch];
+        dg += (double)part[((long long)p * 2 + 1) * c + ch];
+    }
+    if (dgamma) dgamma[ch] = (float)dg;
+    if (dbeta) dbeta[ch] = (float)db;
+    const double s = scale[ch], is = invstd[ch], mu = mean[ch];
+    k1[ch] = (float)(-s * dg * is / count);
+    k0[ch] = (float)(s * (dg * is * mu - db) / count);
+}
+
+__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                int ldx, const float* __restrict__ residual, int ldr, float* __restrict__ out, int ldo, long long m, int cv) {
+    const long long total = m * cv;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / cv;
+        const int c0 = (int)(i % cv) * 4;
+        float4 s = f4(0.f), t = f4(0.f);
+        const bool aff = scale != nullptr;
+        if (aff) { s = ld4(scale + c0); t = ld4(shift + c0); }
+        float4 v = view_apply4(ld4(x + r * ldx + c0), s, t, aff, act);
+        if (residual) add4(v, ld4(residual + r * ldr + c0));
+        st4(out + r * ldo + c0, v);
+    }
+}
+
+__global__ void axpby_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, long long m, int cv, float a, float b) {
+    const long long total = m * cv;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / cv;
+        const int c0 = (int)(i % cv) * 4;
+        float4 s = ld4(src + r * lds + c0);
+        float4 v;
+        if (b != 0.f) {
+            const float4 d = ld4(dst + r * ldd + c0);
+            v = make_float4(fmaf(a, s.x, b * d.x), fmaf(a, s.y, b * d.y), fmaf(a, s.z, b * d.z), fmaf(a, s.w, b * d.w));
+        } else {
+            v = make_float4(a * s.x, a * s.y, a * s.z, a * s.w);
+        }
+        st4(dst + r * ldd + c0, v);
+    }
+}
+
+struct RowLaunch {
+    dim3 grid, block;
+    size_t lds;
+};
+
+void row_launch(long long m, int c, RowGeom* g, RowLaunch* l) {
+    g->m = m; g->c = c; g->cv = c / 4;
+    int bx = g->cv < 256 ? g->cv : 256;
+    int by = 512 / bx;
+    if (by > 64) by = 64;
+    long long want = (m + (long long)by * 8 - 1) / ((long long)by * 8);  // >= 8 rows per thread
+    int gx = (int)(want < MAX_PARTS ? want : MAX_PARTS);
+    if (gx < 1) gx = 1;
+    l->block = dim3(bx, by, 1);
+    l->grid = dim3(gx, cdiv(g->cv, bx), 1);
+    l->lds = (size_t)bx * by * sizeof(float4);
+}
+
+int ew_blocks(long long total) {
+    long long b = (total + 255) / 256;
+    return (int)(b < 4096 ? (b < 1 ? 1 : b) : 4096);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssdseg_bn_finalize(ssdseg_ctx* ctx, const float* stats, int nparts, int c, double count, const float* gamma,
+                       const float* beta, float eps, float momentum, float* moving_mean, float* moving_var, float* mean,
+                       float* invstd, float* scale, float* shift, int training) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(!training || (stats != nullptr && nparts > 0), 2);
+    SSDSEG_ARG(c > 0, 4);
+    SSDSEG_ARG(!training || count >= 1.0, 5);
+    SSDSEG_ARG(gamma != nullptr, 6);
+    SSDSEG_ARG(beta != nullptr, 7);
+    SSDSEG_ARG(training || (moving_mean != nullptr && moving_var != nullptr), 10);
+    SSDSEG_ARG((moving_mean == nullptr) == (moving_var == nullptr), 11);
+    SSDSEG_ARG(scale != nullptr, 14);
+    SSDSEG_ARG(shift != nullptr, 15);
+    const float* src = stats;
+    int np = nparts;
+    if (training && nparts > 256) {
+        // fold the partial rows 64-fold first so the per-channel pass stays short
+        const int slots = 64, len = 2 * c;
+        const int chunk = cdiv(nparts, slots);
+        const int used = cdiv(nparts, chunk);
+        void* ws;
+        int rc = ssdseg_workspace(ctx, (size_t)used * len * sizeof(float), &ws);
+        if (rc) return rc;
+        hipLaunchKernelGGL(fold_parts_kernel, dim3(cdiv(len, 128), used), dim3(128), 0, ctx->stream, stats, nparts, len, chunk, (float*)ws);
+        SSDSEG_LAUNCH_CHECK();
+        src = (const float*)ws;
+        np = used;
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(c, 64)), dim3(64), 0, ctx->stream, src, np, c, count, gamma, beta, eps, momentum,
+                       moving_mean, moving_var, mean, invstd, scale, shift, training);
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+int ssdseg_channel_stats_parts(int m, int c, int* nparts_host) {
+    SSDSEG_ARG(m > 0, 1);
+    SSDSEG_ARG(c > 0 && c % 4 == 0, 2);
+    SSDSEG_ARG(nparts_host != nullptr, 3);
+    RowGeom g;
+    RowLaunch l;
+    row_launch(m, c, &g, &l);
+    *nparts_host = (int)l.grid.x;
+    return 0;
+}
+
+int ssdseg_channel_stats(ssdseg_ctx* ctx, const float* x, int ld, int m, int c, float* stats) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(x != nullptr, 2);
+    SSDSEG_ARG(ld >= c && ld % 4 == 0, 3);
+    SSDSEG_ARG(m > 0, 4);
+    SSDSEG_ARG(c > 0 && c % 4 == 0, 5);
+    SSDSEG_ARG(stats != nullptr, 6);
+    RowGeom g;
+    RowLaunch l;
+    row_launch(m, c, &g, &l);
+    hipLaunchKernelGGL(channel_stats_kernel, l.grid, l.block, l.lds, ctx->stream, x, ld, g, stats);
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+int ssdseg_bn_apply(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const float* residual, int ldr, float* out, int ldo,
+                    int m, int c) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(in != nullptr && in->x != nullptr && ((in->scale == nullptr) == (in->shift == nullptr)), 2);
+    SSDSEG_ARG(ldx >= c && ldx % 4 == 0, 3);
+    SSDSEG_ARG(residual == nullptr || (ldr >= c && ldr % 4 == 0), 5);
+    SSDSEG_ARG(out != nullptr, 6);
+    SSDSEG_ARG(ldo >= c && ldo % 4 == 0, 7);
+    SSDSEG_ARG(m > 0, 8);
+    SSDSEG_ARG(c > 0 && c % 4 == 0, 9);
+    const long long total = (long long)m * (c / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(total)), dim3(256), 0, ctx->stream, in->x, in->scale, in->shift, in->act, ldx,
+                       residual, ldr, out, ldo, (long long)m, c / 4);
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+int ssdseg_bn_bwd_reduce(ssdseg_ctx* ctx, const float* g, int ldg, const float* y, int ldy, int m, int c, const float* scale,
+                         const float* shift, const float* mean, const float* invstd, int act, float* dgamma, float* dbeta,
+                         float* k1, float* k0) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(g != nullptr, 2);
+    SSDSEG_ARG(ldg >= c && ldg % 4 == 0, 3);
+    SSDSEG_ARG(y != nullptr, 4);
+    SSDSEG_ARG(ldy >= c && ldy % 4 == 0, 5);
+    SSDSEG_ARG(m > 0, 6);
+    SSDSEG_ARG(c > 0 && c % 4 == 0, 7);
+    SSDSEG_ARG(scale && shift && mean && invstd, 8);
+    SSDSEG_ARG(k1 != nullptr && k0 != nullptr, 15);
+    RowGeom rg;
+    RowLaunch l;
+    row_launch(m, c, &rg, &l);
+    void* ws;
+    int rc = ssdseg_workspace(ctx, (size_t)l.grid.x * 2 * c * sizeof(float), &ws);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, l.grid, l.block, l.lds, ctx->stream, g, ldg, y, ldy, rg, scale, shift, mean, invstd, act,
+                       (float*)ws);
+    SSDSEG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, 64)), dim3(64), 0, ctx->stream, (const float*)ws, (int)l.grid.x, c, (double)m,
+                       scale, mean, invstd, dgamma, dbeta, k1, k0);
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+int ssdseg_axpby(ssdseg_ctx* ctx, const float* src, int lds, float* dst, int ldd, int m, int c, float a, float b) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(src != nullptr, 2);
+    SSDSEG_ARG(lds >= c && lds % 4 == 0, 3);
+    SSDSEG_ARG(dst != nullptr, 4);
+    SSDSEG_ARG(ldd >= c && ldd % 4 == 0, 5);
+    SSDSEG_ARG(m > 0, 6);
+    SSDSEG_ARG(c > 0 && c % 4 == 0, 7);
+    const long long total = (long long)m * (c / 4);
+    hipLaunchKernelGGL(axpby_kernel, dim3(ew_blocks(total)), dim3(256), 0, ctx->stream, src, lds, dst, ldd, (long long)m, c / 4, a, b);
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

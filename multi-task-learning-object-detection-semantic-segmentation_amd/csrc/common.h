@@ -1,0 +1,108 @@
+// Internal helpers shared by the HIP translation units of libssdseg_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "ssdseg.h"
+
+struct ssdseg_ctx {
+    int device;
+    hipStream_t stream;
+    bool owns_stream;
+    void* workspace;
+    size_t workspace_bytes;
+    int num_cus;
+    bool capturing;
+};
+
+void ssdseg_set_error(const char* fmt, ...);
+int ssdseg_hip_fail(hipError_t e, const char* what);
+// workspace of at least `bytes` (grows with hipMalloc when not capturing; error while capturing)
+int ssdseg_workspace(ssdseg_ctx* ctx, size_t bytes, void** out);
+
+#define SSDSEG_HIP(call)                                      \
+    do {                                                      \
+        hipError_t _e = (call);                               \
+        if (_e != hipSuccess) return ssdseg_hip_fail(_e, #call); \
+    } while (0)
+
+#define SSDSEG_ARG(cond, n)                                               \
+    do {                                                                  \
+        if (!(cond)) {                                                    \
+            ssdseg_set_error("%s: invalid argument %d (%s)", __func__, (n), #cond); \
+            return SSDSEG_EINVAL(n);                                      \
+        }                                                                 \
+    } while (0)
+
+#define SSDSEG_LAUNCH_CHECK()                                   \
+    do {                                                        \
+        hipError_t _e = hipGetLastError();                      \
+        if (_e != hipSuccess) return ssdseg_hip_fail(_e, __func__); \
+    } while (0)
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// TF "SAME" geometry
+static inline void same_pad(int in, int k, int s, int d, int* out, int* before) {
+    int o = (in + s - 1) / s;
+    int keff = (k - 1) * d + 1;
+    int total = (o - 1) * s + keff - in;
+    if (total < 0) total = 0;
+    *out = o;
+    *before = total / 2;
+}
+
+#ifdef __HIPCC__
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Keras ReLU(max_value) forward (App. B.4)
+__device__ __forceinline__ float act_apply(float z, int act) {
+    switch (act) {
+        case SSDSEG_ACT_RELU: return fmaxf(z, 0.f);
+        case SSDSEG_ACT_RELU6: return fminf(fmaxf(z, 0.f), 6.f);
+        case SSDSEG_ACT_ZERO: return 0.f;
+        default: return z;
+    }
+}
+// derivative mask of the activation at pre-activation z
+__device__ __forceinline__ float act_mask(float z, int act) {
+    switch (act) {
+        case SSDSEG_ACT_RELU: return z > 0.f ? 1.f : 0.f;
+        case SSDSEG_ACT_RELU6: return (z > 0.f && z < 6.f) ? 1.f : 0.f;
+        case SSDSEG_ACT_ZERO: return 0.f;
+        default: return 1.f;
+    }
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 f4(float a) { return make_float4(a, a, a, a); }
+
+// a = act(scale*x + shift) on a 4-channel vector; has_affine == false -> act(x)
+__device__ __forceinline__ float4 view_apply4(float4 x, float4 s, float4 t, bool has_affine, int act) {
+    if (has_affine) {
+        x.x = fmaf(s.x, x.x, t.x); x.y = fmaf(s.y, x.y, t.y); x.z = fmaf(s.z, x.z, t.z); x.w = fmaf(s.w, x.w, t.w);
+    }
+    x.x = act_apply(x.x, act); x.y = act_apply(x.y, act); x.z = act_apply(x.z, act); x.w = act_apply(x.w, act);
+    return x;
+}
+
+// dy = s*mask(s*y+t)*g + k1*y + k0 on a 4-channel vector
+__device__ __forceinline__ float4 gview_apply4(float4 g, float4 y, float4 s, float4 t, float4 k1, float4 k0, int act) {
+    float4 r;
+    r.x = fmaf(s.x * act_mask(fmaf(s.x, y.x, t.x), act), g.x, fmaf(k1.x, y.x, k0.x));
+    r.y = fmaf(s.y * act_mask(fmaf(s.y, y.y, t.y), act), g.y, fmaf(k1.y, y.y, k0.y));
+    r.z = fmaf(s.z * act_mask(fmaf(s.z, y.z, t.z), act), g.z, fmaf(k1.z, y.z, k0.z));
+    r.w = fmaf(s.w * act_mask(fmaf(s.w, y.w, t.w), act), g.w, fmaf(k1.w, y.w, k0.w));
+    return r;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+#endif

@@ -1,0 +1,421 @@
+// Depthwise 3x3 convolution, NHWC fp32, TF SAME padding, stride 1|2, dilation >= 1 (stride 1 only when dilated).
+// Replaces DepthwiseConv2D / the depthwise half of SeparableConv2D (reference models.py:88,236,242;
+// blocks.py:33,38,43,122,152) forward and backward.
+//
+// HBM-bound (0.9-2.25 FLOP/B).  Mapping: one thread owns ONE 4-channel vector (16 B) for its whole life, so the
+// 9 filter taps, the producer's BN scale/shift and the BN-stat / dW accumulators live in registers; consecutive
+// lanes hold consecutive channel vectors, i.e. a wave reads whole contiguous NHWC pixels (C*4 bytes each).
+// Each thread walks a grid-strided list of 1x4 output strips and slides a register window along W
+// (18 loads per 4 outputs at stride 1 instead of 36); vertical reuse is left to L1/L2.
+// BatchNorm(train) is fused on both sides: the producer's normalise+ReLU6 is applied on load (ssdseg_view),
+// and this layer's per-channel (sum, sumsq) leave as one partial row per block (no atomics, deterministic).
+#include "common.h"
+
+namespace {
+
+constexpr int TW = 4;           // outputs per strip
+constexpr int MAX_BLOCKS = 2048;
+
+struct DwGeom {
+    int n, h, w, c, ho, wo, s, d, pt, pl;
+    int cv;       // c / 4
+    int wtiles;   // ceil(wo / TW)
+    long long ntiles;
+};
+
+struct ViewDev {
+    const float* x;
+    const float* scale;
+    const float* shift;
+    int act;
+};
+struct GViewDev {
+    const float* g;
+    const float* y;
+    const float* scale;
+    const float* shift;
+    const float* k1;
+    const float* k0;
+    int act;
+};
+
+struct ChanCoef {  // per-thread channel-vector constants
+    float4 s, t, k1, k0;
+    bool affine;
+};
+
+__device__ __forceinline__ float4 load_view(const ViewDev& v, const ChanCoef& cc, long long off) {
+    return view_apply4(ld4(v.x + off), cc.s, cc.t, cc.affine, v.act);
+}
+__device__ __forceinline__ float4 load_gview(const GViewDev& v, const ChanCoef& cc, long long off) {
+    float4 g = ld4(v.g + off);
+    if (!cc.affine) return g;
+    return gview_apply4(g, ld4(v.y + off), cc.s, cc.t, cc.k1, cc.k0, v.act);
+}
+__device__ __forceinline__ void fma4(float4& acc, float4 a, float4 b) {
+    acc.x = fmaf(a.x, b.x, acc.x); acc.y = fmaf(a.y, b.y, acc.y); acc.z = fmaf(a.z, b.z, acc.z); acc.w = fmaf(a.w, b.w, acc.w);
+}
+__device__ __forceinline__ void add4(float4& acc, float4 a) { acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w; }
+
+// block-level reduction over threadIdx.y of one float4 per thread; result valid for threadIdx.y == 0
+__device__ __forceinline__ float4 reduce_over_y(float4 v, float4* red) {
+    __syncthreads();
+    red[threadIdx.y * blockDim.x + threadIdx.x] = v;
+    __syncthreads();
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (threadIdx.y == 0) {
+        for (int y = 0; y < (int)blockDim.y; ++y) add4(r, red[y * blockDim.x + threadIdx.x]);
+    }
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+// S: stride (1|2); DIL: 1 = dense taps with sliding window, 0 = runtime dilation (stride 1), direct gathers.
+template <int S, int DIL>
+__global__ void __launch_bounds__(512) dw_fwd_kernel(DwGeom gm, ViewDev in, const float* __restrict__ wgt,
+                                                     float* __restrict__ y, float* __restrict__ stats) {
+    extern __shared__ float4 red[];
+    const int cvi = blockIdx.y * blockDim.x + threadIdx.x;
+    const bool active = cvi < gm.cv;
+    const int c0 = cvi * 4;
+    float4 wk[9];
+    ChanCoef cc;
+    cc.affine = in.scale != nullptr;
+    cc.s = cc.t = cc.k1 = cc.k0 = f4(0.f);
+    if (active) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wk[t] = ld4(wgt + (long long)t * gm.c + c0);
+        if (cc.affine) { cc.s = ld4(in.scale + c0); cc.t = ld4(in.shift + c0); }
+    }
+    float4 ssum = f4(0.f), ssq = f4(0.f);
+    if (active) {
+        for (long long tile = (long long)blockIdx.x * blockDim.y + threadIdx.y; tile < gm.ntiles;
+             tile += (long long)gridDim.x * blockDim.y) {
+            const int wt = (int)(tile % gm.wtiles);
+            const long long r = tile / gm.wtiles;
+            const int ho = (int)(r % gm.ho);
+            const int n = (int)(r / gm.ho);
+            const int wo0 = wt * TW;
+            float4 out[TW];
+#pragma unroll
+            for (int j = 0; j < TW; ++j) out[j] = f4(0.f);
+            const long long img = (long long)n * gm.h * gm.w;
+            if (DIL == 1) {
+                constexpr int WC = (TW - 1) * S + 3;
+                const int wi0 = wo0 * S - gm.pl;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int hi = ho * S + kh - gm.pt;
+                    if (hi < 0 || hi >= gm.h) continue;
+                    float4 row[WC];
+#pragma unroll
+                    for (int ci = 0; ci < WC; ++ci) {
+                        const int wi = wi0 + ci;
+                        row[ci] = (wi >= 0 && wi < gm.w) ? load_view(in, cc, ((img + (long long)hi * gm.w + wi) * gm.c) + c0)
+                                                         : f4(0.f);
+                    }
+#pragma unroll
+                    for (int j = 0; j < TW; ++j)
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) fma4(out[j], row[j * S + kw], wk[kh * 3 + kw]);
+                }
+            } else {
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int hi = ho + kh * gm.d - gm.pt;
+                    if (hi < 0 || hi >= gm.h) continue;
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+                        for (int j = 0; j < TW; ++j) {
+                            const int wi = wo0 + j + kw * gm.d - gm.pl;
+                            if (wi >= 0 && wi < gm.w && wo0 + j < gm.wo)
+                                fma4(out[j], load_view(in, cc, ((img + (long long)hi * gm.w + wi) * gm.c) + c0), wk[kh * 3 + kw]);
+                        }
+                    }
+                }
+            }
+            const long long obase = (((long long)n * gm.ho + ho) * gm.wo + wo0) * gm.c + c0;
+#pragma unroll
+            for (int j = 0; j < TW; ++j) {
+                if (wo0 + j < gm.wo) {
+                    st4(y + obase + (long long)j * gm.c, out[j]);
+                    add4(ssum, out[j]);
+                    fma4(ssq, out[j], out[j]);
+                }
+            }
+        }
+    }
+    if (stats != nullptr) {
+        float4 a = reduce_over_y(ssum, red);
+        float4 b = reduce_over_y(ssq, red);
+        if (threadIdx.y == 0 && active) {
+            float* row = stats + (long long)blockIdx.x * 2 * gm.c;
+            st4(row + c0, a);
+            st4(row + gm.c + c0, b);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// One pass produces dx (gradient w.r.t. the activated input) and a per-block partial of dW.
+// Each thread owns the output strip (n, ho, wo0..wo0+3) for dW and the input patch rows [ho*S, ho*S+S) x cols
+// [wo0*S, wo0*S + 4*S) for dx; the 3x6 window of dy around the strip serves both.
+template <int S, int DIL, int PT, int PL>
+__global__ void __launch_bounds__(512) dw_bwd_kernel(DwGeom gm, ViewDev in, const float* __restrict__ wgt, GViewDev dy,
+                                                     float* __restrict__ dx, float* __restrict__ dwpart, int accumulate) {
+    extern __shared__ float4 red[];
+    const int cvi = blockIdx.y * blockDim.x + threadIdx.x;
+    const bool active = cvi < gm.cv;
+    const int c0 = cvi * 4;
+    ChanCoef ci, co;  // input-side view coefficients, output-side gradient-view coefficients
+    ci.affine = in.scale != nullptr;
+    co.affine = dy.scale != nullptr;
+    ci.s = ci.t = ci.k1 = ci.k0 = co.s = co.t = co.k1 = co.k0 = f4(0.f);
+    if (active) {
+        if (ci.affine) { ci.s = ld4(in.scale + c0); ci.t = ld4(in.shift + c0); }
+        if (co.affine) { co.s = ld4(dy.scale + c0); co.t = ld4(dy.shift + c0); co.k1 = ld4(dy.k1 + c0); co.k0 = ld4(dy.k0 + c0); }
+    }
+    float4 dwacc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) dwacc[t] = f4(0.f);
+
+    if (active) {
+        for (long long tile = (long long)blockIdx.x * blockDim.y + threadIdx.y; tile < gm.ntiles;
+             tile += (long long)gridDim.x * blockDim.y) {
+            const int wt = (int)(tile % gm.wtiles);
+            const long long r = tile / gm.wtiles;
+            const int ho = (int)(r % gm.ho);
+            const int n = (int)(r / gm.ho);
+            const int wo0 = wt * TW;
+            const long long oimg = (long long)n * gm.ho * gm.wo;
+            const long long iimg = (long long)n * gm.h * gm.w;
+
+            if (DIL == 1) {
+                // ---- dy window rows ho-1..ho+1, cols wo0-1..wo0+TW
+                float4 dyw[3][TW + 2];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const int hh = ho - 1 + a;
+#pragma unroll
+                    for (int b = 0; b < TW + 2; ++b) {
+                        const int ww = wo0 - 1 + b;
+                        dyw[a][b] = (hh >= 0 && hh < gm.ho && ww >= 0 && ww < gm.wo)
+                                        ? load_gview(dy, co, (oimg + (long long)hh * gm.wo + ww) * gm.c + c0)
+                                        : f4(0.f);
+                    }
+                }
+                // ---- dx over the owned input patch
+                if (dx != nullptr) {
+                    float4 wk[9];
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) wk[t] = ld4(wgt + (long long)t * gm.c + c0);
+#pragma unroll
+                    for (int ir = 0; ir < S; ++ir) {
+                        const int hi = ho * S + ir;
+                        if (hi >= gm.h) continue;
+#pragma unroll
+                        for (int ic = 0; ic < TW * S; ++ic) {
+                            const int wi = wo0 * S + ic;
+                            if (wi >= gm.w) continue;
+                            float4 acc = f4(0.f);
+#pragma unroll
+                            for (int kh = 0; kh < 3; ++kh) {
+                                // ho' = (hi + PT - kh) / S must be integral: (ir + PT - kh) % S == 0
+                                if (((ir + PT - kh) % S + S) % S != 0) continue;
+                                const int ra = ((ir + PT - kh) - (((ir + PT - kh) % S + S) % S)) / S + 1;  // window row, compile-time
+#pragma unroll
+                                for (int kw = 0; kw < 3; ++kw) {
+                                    if (((ic + PL - kw) % S + S) % S != 0) continue;
+                                    const int cb = ((ic + PL - kw) - (((ic + PL - kw) % S + S) % S)) / S + 1;  // window col
+                                    if (ra >= 0 && ra < 3 && cb >= 0 && cb < TW + 2) fma4(acc, dyw[ra][cb], wk[kh * 3 + kw]);
+                                }
+                            }
+                            float* p = dx + (iimg + (long long)hi * gm.w + wi) * gm.c + c0;
+                            if (accumulate) add4(acc, ld4(p));
+                            st4(p, acc);
+                        }
+                    }
+                }
+                // ---- dW: a-window row by row against the centre row of dy
+                constexpr int WC = (TW - 1) * S + 3;
+                const int wi0 = wo0 * S - PL;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int hi = ho * S + kh - PT;
+                    if (hi < 0 || hi >= gm.h) continue;
+                    float4 row[WC];
+#pragma unroll
+                    for (int q = 0; q < WC; ++q) {
+                        const int wi = wi0 + q;
+                        row[q] = (wi >= 0 && wi < gm.w) ? load_view(in, ci, (iimg + (long long)hi * gm.w + wi) * gm.c + c0) : f4(0.f);
+                    }
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                        for (int j = 0; j < TW; ++j) fma4(dwacc[kh * 3 + kw], row[j * S + kw], dyw[1][j + 1]);
+                }
+            } else {
+                // dilated, stride 1, pads == dilation: direct gathers
+                const int d = gm.d;
+                float4 wk[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) wk[t] = ld4(wgt + (long long)t * gm.c + c0);
+#pragma unroll
+                for (int j = 0; j < TW; ++j) {
+                    const int wq = wo0 + j;
+                    if (wq >= gm.wo) continue;
+                    const float4 dyc = load_gview(dy, co, (oimg + (long long)ho * gm.wo + wq) * gm.c + c0);
+                    float4 acc = f4(0.f);
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh) {
+                        const int hh = ho + gm.pt - kh * d;   // output row feeding dx at input row ho
+                        const int hi = ho + kh * d - gm.pt;   // input row feeding dW from output row ho
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) {
+                            const int ww = wq + gm.pl - kw * d;
+                            const int wi = wq + kw * d - gm.pl;
+                            if (dx != nullptr && hh >= 0 && hh < gm.ho && ww >= 0 && ww < gm.wo)
+                                fma4(acc, load_gview(dy, co, (oimg + (long long)hh * gm.wo + ww) * gm.c + c0), wk[kh * 3 + kw]);
+                            if (hi >= 0 && hi < gm.h && wi >= 0 && wi < gm.w)
+                                fma4(dwacc[kh * 3 + kw], load_view(in, ci, (iimg + (long long)hi * gm.w + wi) * gm.c + c0), dyc);
+                        }
+                    }
+                    if (dx != nullptr) {
+                        float* p = dx + (iimg + (long long)ho * gm.w + wq) * gm.c + c0;
+                        if (accumulate) add4(acc, ld4(p));
+                        st4(p, acc);
+                    }
+                }
+            }
+        }
+    }
+    // ---- block partial of dW: [gridDim.x][9][c]
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float4 v = reduce_over_y(dwacc[t], red);
+        if (threadIdx.y == 0 && active) st4(dwpart + ((long long)blockIdx.x * 9 + t) * gm.c + c0, v);
+    }
+}
+
+// out[l] = sum_p part[p][l]   (fixed order -> deterministic)
+__global__ void colsum_kernel(const float* __restrict__ part, int nparts, long long len, float* __restrict__ out) {
+    long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= len) return;
+    float acc = 0.f;
+    for (int p = 0; p < nparts; ++p) acc += part[(long long)p * len + l];
+    out[l] = acc;
+}
+
+struct DwLaunch {
+    dim3 grid, block;
+    size_t lds;
+};
+
+bool dw_geometry(int n, int h, int w, int c, int stride, int dilation, DwGeom* g, DwLaunch* l) {
+    g->n = n; g->h = h; g->w = w; g->c = c; g->s = stride; g->d = dilation;
+    same_pad(h, 3, stride, dilation, &g->ho, &g->pt);
+    same_pad(w, 3, stride, dilation, &g->wo, &g->pl);
+    g->cv = c / 4;
+    g->wtiles = cdiv(g->wo, TW);
+    g->ntiles = (long long)n * g->ho * g->wtiles;
+    int bx = g->cv < 256 ? g->cv : 256;
+    int by = 512 / bx;
+    if (by > 64) by = 64;
+    if (by < 1) by = 1;
+    long long want = (g->ntiles + by - 1) / by;
+    int gx = (int)(want < MAX_BLOCKS ? want : MAX_BLOCKS);
+    if (gx < 1) gx = 1;
+    l->block = dim3(bx, by, 1);
+    l->grid = dim3(gx, cdiv(g->cv, bx), 1);
+    l->lds = (size_t)bx * by * sizeof(float4);
+    return true;
+}
+
+}  // namespace
+
+// shared with other translation units
+int ssdseg_colsum(ssdseg_ctx* ctx, const float* part, int nparts, long long len, float* out) {
+    int threads = 256;
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(len, threads)), dim3(threads), 0, ctx->stream, part, nparts, len, out);
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" {
+
+int ssdseg_dwconv_parts(int n, int h, int w, int c, int stride, int* nparts_host) {
+    SSDSEG_ARG(n > 0 && h > 0 && w > 0, 1);
+    SSDSEG_ARG(c > 0 && c % 4 == 0, 4);
+    SSDSEG_ARG(stride == 1 || stride == 2, 5);
+    SSDSEG_ARG(nparts_host != nullptr, 6);
+    DwGeom g;
+    DwLaunch l;
+    dw_geometry(n, h, w, c, stride, 1, &g, &l);  // the strip count does not depend on the dilation
+    *nparts_host = (int)l.grid.x;
+    return 0;
+}
+
+int ssdseg_dwconv_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, float* y, int n, int h, int wdt, int c,
+                      int stride, int dilation, float* stats) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(in != nullptr && in->x != nullptr, 2);
+    SSDSEG_ARG(w != nullptr, 3);
+    SSDSEG_ARG(y != nullptr, 4);
+    SSDSEG_ARG(n > 0, 5);
+    SSDSEG_ARG(h > 0, 6);
+    SSDSEG_ARG(wdt > 0, 7);
+    SSDSEG_ARG(c > 0 && c % 4 == 0, 8);
+    SSDSEG_ARG(stride == 1 || stride == 2, 9);
+    SSDSEG_ARG(dilation >= 1 && (dilation == 1 || stride == 1), 10);
+    SSDSEG_ARG((in->scale == nullptr) == (in->shift == nullptr), 2);
+    DwGeom g;
+    DwLaunch l;
+    dw_geometry(n, h, wdt, c, stride, dilation, &g, &l);
+    ViewDev v{in->x, in->scale, in->shift, in->act};
+    if (dilation == 1 && stride == 1)
+        hipLaunchKernelGGL((dw_fwd_kernel<1, 1>), l.grid, l.block, l.lds, ctx->stream, g, v, w, y, stats);
+    else if (dilation == 1)
+        hipLaunchKernelGGL((dw_fwd_kernel<2, 1>), l.grid, l.block, l.lds, ctx->stream, g, v, w, y, stats);
+    else
+        hipLaunchKernelGGL((dw_fwd_kernel<1, 0>), l.grid, l.block, l.lds, ctx->stream, g, v, w, y, stats);
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+int ssdseg_dwconv_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, const ssdseg_gview* dy, float* dx,
+                      float* dw, int n, int h, int wdt, int c, int stride, int dilation, int accumulate) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(in != nullptr && in->x != nullptr, 2);
+    SSDSEG_ARG(w != nullptr, 3);
+    SSDSEG_ARG(dy != nullptr && dy->g != nullptr, 4);
+    SSDSEG_ARG(dy->scale == nullptr || (dy->y && dy->shift && dy->k1 && dy->k0), 4);
+    SSDSEG_ARG(dw != nullptr, 6);
+    SSDSEG_ARG(n > 0 && h > 0 && wdt > 0, 7);
+    SSDSEG_ARG(c > 0 && c % 4 == 0, 10);
+    SSDSEG_ARG(stride == 1 || stride == 2, 11);
+    SSDSEG_ARG(dilation >= 1 && (dilation == 1 || stride == 1), 12);
+    DwGeom g;
+    DwLaunch l;
+    dw_geometry(n, h, wdt, c, stride, dilation, &g, &l);
+    void* ws;
+    size_t part_bytes = (size_t)l.grid.x * 9 * c * sizeof(float);
+    int rc = ssdseg_workspace(ctx, part_bytes, &ws);
+    if (rc) return rc;
+    float* part = (float*)ws;
+    ViewDev v{in->x, in->scale, in->shift, in->act};
+    GViewDev gv{dy->g, dy->y, dy->scale, dy->shift, dy->k1, dy->k0, dy->act};
+#define DW_BWD(S_, D_, PT_, PL_) \
+    hipLaunchKernelGGL((dw_bwd_kernel<S_, D_, PT_, PL_>), l.grid, l.block, l.lds, ctx->stream, g, v, w, gv, dx, part, accumulate)
+    if (dilation != 1) DW_BWD(1, 0, 0, 0);
+    else if (stride == 1) DW_BWD(1, 1, 1, 1);
+    else if (g.pt == 0 && g.pl == 0) DW_BWD(2, 1, 0, 0);
+    else if (g.pt == 0 && g.pl == 1) DW_BWD(2, 1, 0, 1);
+    else if (g.pt == 1 && g.pl == 0) DW_BWD(2, 1, 1, 0);
+    else DW_BWD(2, 1, 1, 1);
+#undef DW_BWD
+    SSDSEG_LAUNCH_CHECK();
+    return ssdseg_colsum(ctx, part, (int)l.grid.x, 9LL * c, dw);
+}
+
+}  // extern "C"

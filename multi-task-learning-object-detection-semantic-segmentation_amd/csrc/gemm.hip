@@ -1,0 +1,506 @@
+// Pointwise (1x1) convolution as GEMM on the fp32-input matrix cores (v_mfma_f32_32x32x2_f32: exact fp32
+// products, fp32 accumulate -- the only MFMA dtype that keeps 1e-3 rel through ~60 layers without operand
+// splitting).  Replaces Conv2D 1x1 / the pointwise half of SeparableConv2D (reference models.py:65,110;
+// blocks.py:28,58,70,109) forward, backward-data and backward-weight.
+//
+//   fwd        y[m][n]  = sum_k act(scale_k*x[m][k]+shift_k) * w[k][n]         + per-channel (sum,sumsq) partials
+//   bwd_data   dx[m][k] = sum_n dy[m][n] * w[k][n]   (+ residual, + accumulate)  dy formed on load (BN backward)
+//   bwd_weight dw[k][n] = sum_m a[m][k] * dy[m][n]                               split over m, fixed-order reduce
+//
+// fwd/bwd_data share one kernel ("rowA": the streamed operand is row-major with the reduction axis contiguous).
+// Tile: 128 rows x (32*WN) cols per 256-thread block, BK = 32.  The streamed operand is staged through LDS as
+// [128][32+4] so that each lane fetches 4 consecutive k with one conflict-free ds_read_b128; since a GEMM may
+// visit k in any order, MFMA #jj of a group takes k = 8*kk + jj from lanes 0-31 and k = 8*kk + 4 + jj from lanes
+// 32-63 (for A and B alike).  The weight tile sits in LDS as [32][BN+1] and is read with conflict-free ds_read_b32.
+// The next tile's global loads are issued before the current tile's MFMAs (register prefetch).
+#include "common.h"
+
+int ssdseg_colsum(ssdseg_ctx* ctx, const float* part, int nparts, long long len, float* out);
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+constexpr int AS = BK + 4;
+
+struct RowAArgs {
+    const float* a0;   // x (fwd) | g (bwd_data)
+    const float* a1;   // unused  | y
+    const float* cs;   // per-reduction-channel coefficients (nullable -> identity)
+    const float* ct;
+    const float* ck1;
+    const float* ck0;
+    int act;
+    int lda;
+    const float* b;
+    int ldb;
+    float* out;
+    int ldo;
+    const float* residual;
+    int ldr;
+    int accumulate;
+    float* stats;
+    int I, R, J;
+};
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+template <int WN, int MODE>
+__global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
+    constexpr int BN = 32 * WN;
+    constexpr int BS = BN + 1;
+    extern __shared__ float smem[];
+    float* As = smem;                 // [BM][AS]
+    float* Bs = smem + BM * AS;       // [BK][BS]
+
+    const int t = threadIdx.x;
+    const int wave = t >> 6, lane = t & 63, li = lane & 31, hh = lane >> 5;
+    const int m0 = blockIdx.y * BM;
+    const int j0 = blockIdx.x * BN;
+    const int KT = (p.R + BK - 1) / BK;
+    const bool affine = p.cs != nullptr;
+
+    const int a_c4 = t & 7;
+    const int a_r = t >> 3;
+    float4 areg[4];
+    float4 breg[WN];
+
+    auto load_tiles = [&](int kt) {
+        const int r = kt * BK + a_c4 * 4;
+        const bool rin = r < p.R;
+        float4 cs = f4(0.f), ct = f4(0.f), ck1 = f4(0.f), ck0 = f4(0.f);
+        if (affine && rin) {
+            cs = ld4(p.cs + r);
+            ct = ld4(p.ct + r);
+            if (MODE == 1) { ck1 = ld4(p.ck1 + r); ck0 = ld4(p.ck0 + r); }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + a_r + 32 * i;
+            float4 v = f4(0.f);
+            if (rin && m < p.I) {
+                const long long off = (long long)m * p.lda + r;
+                if (MODE == 0) {
+                    v = view_apply4(ld4(p.a0 + off), cs, ct, affine, p.act);
+                } else {
+                    v = ld4(p.a0 + off);
+                    if (affine) v = gview_apply4(v, ld4(p.a1 + off), cs, ct, ck1, ck0, p.act);
+                }
+            }
+            areg[i] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < WN; ++q) {
+            const int idx = t + 256 * q;
+            float4 v = f4(0.f);
+            if (MODE == 0) {
+                const int rr = idx / (8 * WN), j4 = idx % (8 * WN);
+                const int gr = kt * BK + rr, gj = j0 + j4 * 4;
+                if (gr < p.R && gj < p.J) v = ld4(p.b + (long long)gr * p.ldb + gj);
+            } else {
+                const int jj = idx >> 3, r4 = idx & 7;
+                const int gr = kt * BK + r4 * 4, gj = j0 + jj;
+                if (gr < p.R && gj < p.J) v = ld4(p.b + (long long)gj * p.ldb + gr);
+            }
+            breg[q] = v;
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) st4(As + (a_r + 32 * i) * AS + a_c4 * 4, areg[i]);
+#pragma unroll
+        for (int q = 0; q < WN; ++q) {
+            const int idx = t + 256 * q;
+            if (MODE == 0) {
+                const int rr = idx / (8 * WN), j4 = idx % (8 * WN);
+                float* d = Bs + rr * BS + j4 * 4;
+                d[0] = breg[q].x; d[1] = breg[q].y; d[2] = breg[q].z; d[3] = breg[q].w;
+            } else {
+                const int jj = idx >> 3, r4 = idx & 7;
+                float* d = Bs + (r4 * 4) * BS + jj;
+                d[0] = breg[q].x; d[BS] = breg[q].y; d[2 * BS] = breg[q].z; d[3 * BS] = breg[q].w;
+            }
+        }
+    };
+
+    f32x16 acc[WN];
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+
+    load_tiles(0);
+    for (int kt = 0; kt < KT; ++kt) {
+        __syncthreads();
+        store_tiles();
+        __syncthreads();
+        if (kt + 1 < KT) load_tiles(kt + 1);
+        const float* arow = As + (wave * 32 + li) * AS + 4 * hh;
+        const float* bcol = Bs + (4 * hh) * BS + li;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const float4 a4 = ld4(arow + kk * 8);
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+                for (int nt = 0; nt < WN; ++nt) {
+                    const float bv = bcol[(kk * 8 + jj) * BS + nt * 32];
+                    acc[nt] = mfma32(av[jj], bv, acc[nt]);
+                }
+            }
+        }
+    }
+
+    // ---------------- epilogue: C/D layout col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt) {
+        const int j = j0 + nt * 32 + li;
+        if (j < p.J) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                if (m < p.I) {
+                    float v = acc[nt][e];
+                    if (MODE == 1) {
+                        if (p.residual) v += p.residual[(long long)m * p.ldr + j];
+                        if (p.accumulate) v += p.out[(long long)m * p.ldo + j];
+                    }
+                    p.out[(long long)m * p.ldo + j] = v;
+                }
+            }
+        }
+    }
+    if (MODE == 0 && p.stats != nullptr) {
+        // per-channel (sum, sumsq) of this 128-row tile; padded rows are exactly zero
+        __syncthreads();
+        float* red = smem;  // [4 waves][2][BN]
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { s += acc[nt][e]; q = fmaf(acc[nt][e], acc[nt][e], q); }
+            s += __shfl_xor(s, 32, 64);
+            q += __shfl_xor(q, 32, 64);
+            if (hh == 0) {
+                red[(wave * 2 + 0) * BN + nt * 32 + li] = s;
+                red[(wave * 2 + 1) * BN + nt * 32 + li] = q;
+            }
+        }
+        __syncthreads();
+        for (int idx = t; idx < 2 * BN; idx += 256) {
+            const int which = idx / BN, jl = idx % BN;
+            const int j = j0 + jl;
+            if (j < p.J) {
+                float v = red[(0 * 2 + which) * BN + jl] + red[(1 * 2 + which) * BN + jl] + red[(2 * 2 + which) * BN + jl] +
+                          red[(3 * 2 + which) * BN + jl];
+                p.stats[((long long)blockIdx.y * 2 + which) * p.J + j] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ bwd_weight
+struct WGradArgs {
+    const float* x;  // view over [M][K]
+    const float* xs;
+    const float* xt;
+    int xact;
+    int ldx;
+    const float* g;  // gview over [M][N]
+    const float* y;
+    const float* gs;
+    const float* gt;
+    const float* gk1;
+    const float* gk0;
+    int gact;
+    int ldy;
+    float* part;  // [P][K][N]
+    int M, K, N;
+    int rows_per_split;
+};
+
+constexpr int RW = 16;  // reduction rows per wave per step
+
+// WI waves along the output rows (k), WR waves splitting the reduction rows (m); WI*WR == 4.
+template <int WI, int WR, int WN>
+__global__ void __launch_bounds__(256) gemm_wgrad_kernel(WGradArgs p) {
+    constexpr int BI = 32 * WI, BJ = 32 * WN, BRT = RW * WR;
+    extern __shared__ float smem[];
+    float* Xs = smem;              // [BRT][BI]
+    float* Ys = smem + BRT * BI;   // [BRT][BJ]
+    const int t = threadIdx.x;
+    const int wave = t >> 6, lane = t & 63, li = lane & 31, hh = lane >> 5;
+    const int wi = wave % WI, wr = wave / WI;
+    const int i0 = blockIdx.y * BI;   // k offset
+    const int j0 = blockIdx.x * BJ;   // n offset
+    const int split = blockIdx.z;
+    const long long mbeg = (long long)split * p.rows_per_split;
+    long long mend = mbeg + p.rows_per_split;
+    if (mend > p.M) mend = p.M;
+    const bool xaff = p.xs != nullptr, gaff = p.gs != nullptr;
+
+    constexpr int XV = BRT * BI / 4;   // float4 per X tile (== 256 * 2)
+    constexpr int YV = BRT * BJ / 4;
+    constexpr int XQ = (XV + 255) / 256, YQ = (YV + 255) / 256;
+    float4 xreg[XQ], yreg[YQ];
+
+    // per-thread channel coefficients are fixed across steps when the tile width divides 256 float4 columns;
+    // otherwise they are re-read per step (they sit in L1).
+    auto load_tiles = [&](long long mrow) {
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            const int idx = t + 256 * q;
+            float4 v = f4(0.f);
+            if (idx < XV) {
+                const int rr = idx / (BI / 4), c4 = idx % (BI / 4);
+                const long long m = mrow + rr;
+                const int k = i0 + c4 * 4;
+                if (m < mend && k < p.K) {
+                    float4 s = f4(0.f), sh = f4(0.f);
+                    if (xaff) { s = ld4(p.xs + k); sh = ld4(p.xt + k); }
+                    v = view_apply4(ld4(p.x + m * p.ldx + k), s, sh, xaff, p.xact);
+                }
+            }
+            xreg[q] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < YQ; ++q) {
+            const int idx = t + 256 * q;
+            float4 v = f4(0.f);
+            if (idx < YV) {
+                const int rr = idx / (BJ / 4), c4 = idx % (BJ / 4);
+                const long long m = mrow + rr;
+                const int n = j0 + c4 * 4;
+                if (m < mend && n < p.N) {
+                    v = ld4(p.g + m * p.ldy + n);
+                    if (gaff) v = gview_apply4(v, ld4(p.y + m * p.ldy + n), ld4(p.gs + n), ld4(p.gt + n), ld4(p.gk1 + n), ld4(p.gk0 + n), p.gact);
+                }
+            }
+            yreg[q] = v;
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            const int idx = t + 256 * q;
+            if (idx < XV) st4(Xs + idx * 4, xreg[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < YQ; ++q) {
+            const int idx = t + 256 * q;
+            if (idx < YV) st4(Ys + idx * 4, yreg[q]);
+        }
+    };
+
+    f32x16 acc[WN];
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+
+    if (mbeg < mend) load_tiles(mbeg);
+    for (long long mrow = mbeg; mrow < mend; mrow += BRT) {
+        __syncthreads();
+        store_tiles();
+        __syncthreads();
+        if (mrow + BRT < mend) load_tiles(mrow + BRT);
+        const float* xa = Xs + (wr * RW + hh) * BI + wi * 32 + li;
+        const float* yb = Ys + (wr * RW + hh) * BJ + li;
+#pragma unroll
+        for (int st = 0; st < RW / 2; ++st) {
+            const float av = xa[(2 * st) * BI];
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt) acc[nt] = mfma32(av, yb[(2 * st) * BJ + nt * 32], acc[nt]);
+        }
+    }
+
+    // reduce the WR reduction-waves through LDS, then write the split's partial tile
+    float* out = p.part + (long long)split * p.K * p.N;
+    if (WR > 1) {
+        __syncthreads();
+        float* red = smem;  // [WR-1][WI][WN][16][64]
+        if (wr > 0) {
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) red[((((wr - 1) * WI + wi) * WN + nt) * 16 + e) * 64 + lane] = acc[nt][e];
+        }
+        __syncthreads();
+        if (wr == 0) {
+#pragma unroll
+            for (int q = 1; q < WR; ++q)
+#pragma unroll
+                for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[nt][e] += red[((((q - 1) * WI + wi) * WN + nt) * 16 + e) * 64 + lane];
+        }
+    }
+    if (wr == 0) {
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) {
+            const int n = j0 + nt * 32 + li;
+            if (n < p.N) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int k = i0 + wi * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    if (k < p.K) out[(long long)k * p.N + n] = acc[nt][e];
+                }
+            }
+        }
+    }
+}
+
+// pick the column-tile width (in 32-col MFMA tiles) that wastes the fewest padded columns; ties -> wider
+int pick_wn(int n) {
+    int best = 1;
+    long long best_pad = -1;
+    for (int wn = 1; wn <= 5; ++wn) {
+        long long tiles = (n + 32 * wn - 1) / (32 * wn);
+        long long pad = tiles * 32 * wn;
+        if (best_pad < 0 || pad <= best_pad) { best_pad = pad; best = wn; }
+    }
+    return best;
+}
+
+template <int MODE>
+int launch_rowA(ssdseg_ctx* ctx, const RowAArgs& a) {
+    const int wn = pick_wn(a.J);
+    dim3 grid(cdiv(a.J, 32 * wn), cdiv(a.I, BM), 1);
+    if (grid.y > 65535) { ssdseg_set_error("gemm: too many row tiles (%u)", grid.y); return SSDSEG_EINVAL(0); }
+    size_t lds = (size_t)(BM * AS + BK * (32 * wn + 1)) * sizeof(float);
+    size_t red = (size_t)(4 * 2 * 32 * wn) * sizeof(float);
+    if (red > lds) lds = red;
+    switch (wn) {
+        case 1: hipLaunchKernelGGL((gemm_rowA_kernel<1, MODE>), grid, dim3(256), lds, ctx->stream, a); break;
+        case 2: hipLaunchKernelGGL((gemm_rowA_kernel<2, MODE>), grid, dim3(256), lds, ctx->stream, a); break;
+        case 3: hipLaunchKernelGGL((gemm_rowA_kernel<3, MODE>), grid, dim3(256), lds, ctx->stream, a); break;
+        case 4: hipLaunchKernelGGL((gemm_rowA_kernel<4, MODE>), grid, dim3(256), lds, ctx->stream, a); break;
+        default: hipLaunchKernelGGL((gemm_rowA_kernel<5, MODE>), grid, dim3(256), lds, ctx->stream, a); break;
+    }
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int WI, int WR>
+int launch_wgrad_wn(ssdseg_ctx* ctx, const WGradArgs& a, int wn, dim3 grid) {
+    size_t lds = (size_t)(RW * WR) * (32 * WI + 32 * wn) * sizeof(float);
+    size_t red = (size_t)(WR - 1) * WI * wn * 16 * 64 * sizeof(float);
+    if (red > lds) lds = red;
+    switch (wn) {
+        case 1: hipLaunchKernelGGL((gemm_wgrad_kernel<WI, WR, 1>), grid, dim3(256), lds, ctx->stream, a); break;
+        case 2: hipLaunchKernelGGL((gemm_wgrad_kernel<WI, WR, 2>), grid, dim3(256), lds, ctx->stream, a); break;
+        case 3: hipLaunchKernelGGL((gemm_wgrad_kernel<WI, WR, 3>), grid, dim3(256), lds, ctx->stream, a); break;
+        case 4: hipLaunchKernelGGL((gemm_wgrad_kernel<WI, WR, 4>), grid, dim3(256), lds, ctx->stream, a); break;
+        default: hipLaunchKernelGGL((gemm_wgrad_kernel<WI, WR, 5>), grid, dim3(256), lds, ctx->stream, a); break;
+    }
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssdseg_pwconv_parts(int m, int n, int* nparts_host) {
+    SSDSEG_ARG(m > 0, 1);
+    SSDSEG_ARG(n > 0, 2);
+    SSDSEG_ARG(nparts_host != nullptr, 3);
+    *nparts_host = cdiv(m, BM);
+    return 0;
+}
+
+int ssdseg_pwconv_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const float* w, float* y, int ldy, int m, int k,
+                      int n, float* stats) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(in != nullptr && in->x != nullptr && ((in->scale == nullptr) == (in->shift == nullptr)), 2);
+    SSDSEG_ARG(ldx >= k && ldx % 4 == 0, 3);
+    SSDSEG_ARG(w != nullptr, 4);
+    SSDSEG_ARG(y != nullptr, 5);
+    SSDSEG_ARG(ldy >= n, 6);
+    SSDSEG_ARG(m > 0, 7);
+    SSDSEG_ARG(k > 0 && k % 4 == 0, 8);
+    SSDSEG_ARG(n > 0 && n % 4 == 0, 9);
+    RowAArgs a{};
+    a.a0 = in->x; a.cs = in->scale; a.ct = in->shift; a.act = in->act; a.lda = ldx;
+    a.b = w; a.ldb = n;
+    a.out = y; a.ldo = ldy;
+    a.stats = stats;
+    a.I = m; a.R = k; a.J = n;
+    return launch_rowA<0>(ctx, a);
+}
+
+int ssdseg_pwconv_bwd_data(ssdseg_ctx* ctx, const ssdseg_gview* dy, int ldy, const float* w, float* dx, int ldx, int m,
+                           int k, int n, const float* residual, int ldr, int accumulate) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(dy != nullptr && dy->g != nullptr, 2);
+    SSDSEG_ARG(dy->scale == nullptr || (dy->y && dy->shift && dy->k1 && dy->k0), 2);
+    SSDSEG_ARG(ldy >= n && ldy % 4 == 0, 3);
+    SSDSEG_ARG(w != nullptr, 4);
+    SSDSEG_ARG(dx != nullptr, 5);
+    SSDSEG_ARG(ldx >= k, 6);
+    SSDSEG_ARG(m > 0, 7);
+    SSDSEG_ARG(k > 0 && k % 4 == 0, 8);
+    SSDSEG_ARG(n > 0 && n % 4 == 0, 9);
+    SSDSEG_ARG(residual == nullptr || ldr >= k, 11);
+    RowAArgs a{};
+    a.a0 = dy->g; a.a1 = dy->y; a.cs = dy->scale; a.ct = dy->shift; a.ck1 = dy->k1; a.ck0 = dy->k0; a.act = dy->act;
+    a.lda = ldy;
+    a.b = w; a.ldb = n;
+    a.out = dx; a.ldo = ldx;
+    a.residual = residual; a.ldr = ldr; a.accumulate = accumulate;
+    a.I = m; a.R = n; a.J = k;
+    return launch_rowA<1>(ctx, a);
+}
+
+int ssdseg_pwconv_bwd_weight(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssdseg_gview* dy, int ldy, float* dw,
+                             int m, int k, int n) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(in != nullptr && in->x != nullptr && ((in->scale == nullptr) == (in->shift == nullptr)), 2);
+    SSDSEG_ARG(ldx >= k && ldx % 4 == 0, 3);
+    SSDSEG_ARG(dy != nullptr && dy->g != nullptr, 4);
+    SSDSEG_ARG(dy->scale == nullptr || (dy->y && dy->shift && dy->k1 && dy->k0), 4);
+    SSDSEG_ARG(ldy >= n && ldy % 4 == 0, 5);
+    SSDSEG_ARG(dw != nullptr, 6);
+    SSDSEG_ARG(m > 0, 7);
+    SSDSEG_ARG(k > 0 && k % 4 == 0, 8);
+    SSDSEG_ARG(n > 0 && n % 4 == 0, 9);
+    const int wn = pick_wn(n);
+    const int wi = k <= 32 ? 1 : (k <= 64 ? 2 : 4);
+    const int wr = 4 / wi;
+    const int brt = RW * wr;
+    const int itiles = cdiv(k, 32 * wi), jtiles = cdiv(n, 32 * wn);
+    long long steps = ((long long)m + brt - 1) / brt;
+    long long want = (4LL * ctx->num_cus + (long long)itiles * jtiles - 1) / ((long long)itiles * jtiles);
+    long long max_splits = (steps + 3) / 4;  // at least 4 steps per block
+    long long splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
+    if (splits > 65535) splits = 65535;
+    long long steps_per_split = (steps + splits - 1) / splits;
+    splits = (steps + steps_per_split - 1) / steps_per_split;
+    WGradArgs a{};
+    a.x = in->x; a.xs = in->scale; a.xt = in->shift; a.xact = in->act; a.ldx = ldx;
+    a.g = dy->g; a.y = dy->y; a.gs = dy->scale; a.gt = dy->shift; a.gk1 = dy->k1; a.gk0 = dy->k0; a.gact = dy->act;
+    a.ldy = ldy;
+    a.M = m; a.K = k; a.N = n;
+    a.rows_per_split = (int)(steps_per_split * brt);
+    float* part = dw;
+    if (splits > 1) {
+        void* ws;
+        int rc = ssdseg_workspace(ctx, (size_t)splits * k * n * sizeof(float), &ws);
+        if (rc) return rc;
+        part = (float*)ws;
+    }
+    a.part = part;
+    dim3 grid(jtiles, itiles, (unsigned)splits);
+    int rc;
+    if (wi == 1) rc = launch_wgrad_wn<1, 4>(ctx, a, wn, grid);
+    else if (wi == 2) rc = launch_wgrad_wn<2, 2>(ctx, a, wn, grid);
+    else rc = launch_wgrad_wn<4, 1>(ctx, a, wn, grid);
+    if (rc) return rc;
+    if (splits > 1) return ssdseg_colsum(ctx, part, (int)splits, (long long)k * n, dw);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,236 @@
+// Context, device memory, events and hipGraph capture behind the C-ABI (include/ssdseg.h).
+#include <stdarg.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void ssdseg_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int ssdseg_hip_fail(hipError_t e, const char* what) {
+    ssdseg_set_error("%s: %s (%d)", what, hipGetErrorString(e), (int)e);
+    return -(int)e;
+}
+
+int ssdseg_workspace(ssdseg_ctx* ctx, size_t bytes, void** out) {
+    if (bytes > ctx->workspace_bytes) {
+        if (ctx->capturing) {
+            ssdseg_set_error("workspace of %zu bytes needed during graph capture (have %zu): call ssdseg_ctx_reserve first",
+                             bytes, ctx->workspace_bytes);
+            return SSDSEG_EINVAL(0);
+        }
+        // the old workspace may still be in use by queued kernels
+        SSDSEG_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->workspace) SSDSEG_HIP(hipFree(ctx->workspace));
+        ctx->workspace = nullptr;
+        ctx->workspace_bytes = 0;
+        size_t want = bytes + bytes / 4;
+        SSDSEG_HIP(hipMalloc(&ctx->workspace, want));
+        ctx->workspace_bytes = want;
+    }
+    *out = ctx->workspace;
+    return 0;
+}
+
+extern "C" {
+
+const char* ssdseg_last_error(void) { return g_err; }
+int ssdseg_version(void) { return SSDSEG_VERSION; }
+
+int ssdseg_device_count(int* count_host) {
+    SSDSEG_ARG(count_host != nullptr, 1);
+    SSDSEG_HIP(hipGetDeviceCount(count_host));
+    return 0;
+}
+
+int ssdseg_ctx_create(int device, void* stream, ssdseg_ctx** out_host) {
+    SSDSEG_ARG(out_host != nullptr, 3);
+    int count = 0;
+    SSDSEG_HIP(hipGetDeviceCount(&count));
+    SSDSEG_ARG(device >= 0 && device < count, 1);
+    SSDSEG_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    SSDSEG_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        ssdseg_set_error("libssdseg_hip is built for gfx950 (MI355X) only; device %d is %s", device, prop.gcnArchName);
+        return SSDSEG_EINVAL(1);
+    }
+    ssdseg_ctx* c = new ssdseg_ctx();
+    c->device = device;
+    c->workspace = nullptr;
+    c->workspace_bytes = 0;
+    c->num_cus = prop.multiProcessorCount;
+    c->capturing = false;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+        c->owns_stream = false;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete c;
+            return ssdseg_hip_fail(e, "hipStreamCreateWithFlags");
+        }
+        c->owns_stream = true;
+    }
+    *out_host = c;
+    return 0;
+}
+
+int ssdseg_ctx_destroy(ssdseg_ctx* ctx) {
+    if (!ctx) return 0;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    if (ctx->workspace) hipFree(ctx->workspace);
+    if (ctx->owns_stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return 0;
+}
+
+int ssdseg_ctx_sync(ssdseg_ctx* ctx) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int ssdseg_ctx_reserve(ssdseg_ctx* ctx, size_t workspace_bytes) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    void* p;
+    return ssdseg_workspace(ctx, workspace_bytes, &p);
+}
+
+int ssdseg_ctx_device_name(ssdseg_ctx* ctx, char* buf_host, size_t buf_len) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(buf_host != nullptr && buf_len > 0, 2);
+    hipDeviceProp_t prop;
+    SSDSEG_HIP(hipGetDeviceProperties(&prop, ctx->device));
+    snprintf(buf_host, buf_len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return 0;
+}
+
+int ssdseg_malloc(ssdseg_ctx* ctx, size_t bytes, void** out_host) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(out_host != nullptr, 3);
+    SSDSEG_HIP(hipSetDevice(ctx->device));
+    *out_host = nullptr;
+    if (bytes == 0) return 0;
+    SSDSEG_HIP(hipMalloc(out_host, bytes));
+    return 0;
+}
+
+int ssdseg_free(ssdseg_ctx* ctx, void* ptr) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    if (ptr) SSDSEG_HIP(hipFree(ptr));
+    return 0;
+}
+
+int ssdseg_memcpy_h2d(ssdseg_ctx* ctx, void* dst, const void* src_host, size_t bytes) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    if (bytes == 0) return 0;
+    SSDSEG_ARG(dst != nullptr, 2);
+    SSDSEG_ARG(src_host != nullptr, 3);
+    SSDSEG_HIP(hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SSDSEG_HIP(hipStreamSynchronize(ctx->stream));  // pageable host memory: the caller may reuse it
+    return 0;
+}
+
+int ssdseg_memcpy_d2h(ssdseg_ctx* ctx, void* dst_host, const void* src, size_t bytes) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    if (bytes == 0) return 0;
+    SSDSEG_ARG(dst_host != nullptr, 2);
+    SSDSEG_ARG(src != nullptr, 3);
+    SSDSEG_HIP(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SSDSEG_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int ssdseg_memcpy_d2d(ssdseg_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    if (bytes == 0) return 0;
+    SSDSEG_ARG(dst != nullptr, 2);
+    SSDSEG_ARG(src != nullptr, 3);
+    SSDSEG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+}
+
+int ssdseg_memset(ssdseg_ctx* ctx, void* dst, int value, size_t bytes) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    if (bytes == 0) return 0;
+    SSDSEG_ARG(dst != nullptr, 2);
+    SSDSEG_HIP(hipMemsetAsync(dst, value, bytes, ctx->stream));
+    return 0;
+}
+
+int ssdseg_event_create(ssdseg_ctx* ctx, void** out_host) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(out_host != nullptr, 2);
+    hipEvent_t ev;
+    SSDSEG_HIP(hipEventCreate(&ev));
+    *out_host = (void*)ev;
+    return 0;
+}
+
+int ssdseg_event_destroy(ssdseg_ctx* ctx, void* ev) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    if (ev) SSDSEG_HIP(hipEventDestroy((hipEvent_t)ev));
+    return 0;
+}
+
+int ssdseg_event_record(ssdseg_ctx* ctx, void* ev) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(ev != nullptr, 2);
+    SSDSEG_HIP(hipEventRecord((hipEvent_t)ev, ctx->stream));
+    return 0;
+}
+
+int ssdseg_event_elapsed_ms(ssdseg_ctx* ctx, void* ev_start, void* ev_stop, float* ms_host) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(ev_start != nullptr, 2);
+    SSDSEG_ARG(ev_stop != nullptr, 3);
+    SSDSEG_ARG(ms_host != nullptr, 4);
+    SSDSEG_HIP(hipEventSynchronize((hipEvent_t)ev_stop));
+    SSDSEG_HIP(hipEventElapsedTime(ms_host, (hipEvent_t)ev_start, (hipEvent_t)ev_stop));
+    return 0;
+}
+
+int ssdseg_graph_begin(ssdseg_ctx* ctx) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(!ctx->capturing, 1);
+    SSDSEG_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    ctx->capturing = true;
+    return 0;
+}
+
+int ssdseg_graph_end(ssdseg_ctx* ctx, void** graph_exec_host) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(graph_exec_host != nullptr, 2);
+    SSDSEG_ARG(ctx->capturing, 1);
+    ctx->capturing = false;
+    hipGraph_t graph = nullptr;
+    SSDSEG_HIP(hipStreamEndCapture(ctx->stream, &graph));
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e != hipSuccess) return ssdseg_hip_fail(e, "hipGraphInstantiate");
+    *graph_exec_host = (void*)exec;
+    return 0;
+}
+
+int ssdseg_graph_launch(ssdseg_ctx* ctx, void* graph_exec) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(graph_exec != nullptr, 2);
+    SSDSEG_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, ctx->stream));
+    return 0;
+}
+
+int ssdseg_graph_destroy(ssdseg_ctx* ctx, void* graph_exec) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    if (graph_exec) SSDSEG_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,334 @@
+"""ctypes binding of libssdseg_hip.so (C-ABI: include/ssdseg.h) -- the only door from the Python host to the GPU.
+
+No torch, no fallbacks: if the shared library is missing or a call fails this module raises.  Device memory is
+owned by `DeviceBuffer` objects (hipMalloc/hipFree through the C-ABI), or borrowed from a raw pointer (for the
+RCCL plumbing, where the gradient bucket is a torch tensor).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+_LIB_NAME = "libssdseg_hip.so"
+_lib = None
+
+ACT_NONE, ACT_RELU, ACT_RELU6, ACT_ZERO = 0, 1, 2, 3
+
+
+class SsdsegError(RuntimeError):
+    pass
+
+
+class ViewStruct(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("act", C.c_int32), ("_pad", C.c_int32)]
+
+
+class GViewStruct(C.Structure):
+    _fields_ = [("g", C.c_void_p), ("y", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
+                ("k1", C.c_void_p), ("k0", C.c_void_p), ("act", C.c_int32), ("_pad", C.c_int32)]
+
+
+_vp, _i, _f, _d, _sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
+_VP = C.POINTER(ViewStruct)
+_GP = C.POINTER(GViewStruct)
+_ip = C.POINTER(C.c_int)
+
+# name -> argtypes (restype is always int, except the two below)
+_SIGNATURES = {
+    "ssdseg_device_count": [_ip],
+    "ssdseg_ctx_create": [_i, _vp, C.POINTER(_vp)],
+    "ssdseg_ctx_destroy": [_vp],
+    "ssdseg_ctx_sync": [_vp],
+    "ssdseg_ctx_reserve": [_vp, _sz],
+    "ssdseg_ctx_device_name": [_vp, C.c_char_p, _sz],
+    "ssdseg_malloc": [_vp, _sz, C.POINTER(_vp)],
+    "ssdseg_free": [_vp, _vp],
+    "ssdseg_memcpy_h2d": [_vp, _vp, _vp, _sz],
+    "ssdseg_memcpy_d2h": [_vp, _vp, _vp, _sz],
+    "ssdseg_memcpy_d2d": [_vp, _vp, _vp, _sz],
+    "ssdseg_memset": [_vp, _vp, _i, _sz],
+    "ssdseg_event_create": [_vp, C.POINTER(_vp)],
+    "ssdseg_event_destroy": [_vp, _vp],
+    "ssdseg_event_record": [_vp, _vp],
+    "ssdseg_event_elapsed_ms": [_vp, _vp, _vp, C.POINTER(_f)],
+    "ssdseg_graph_begin": [_vp],
+    "ssdseg_graph_end": [_vp, C.POINTER(_vp)],
+    "ssdseg_graph_launch": [_vp, _vp],
+    "ssdseg_graph_destroy": [_vp, _vp],
+    "ssdseg_stem_conv_parts": [_i, _i, _i, _i, _ip],
+    "ssdseg_stem_conv_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp],
+    "ssdseg_stem_conv_bwd_weight": [_vp, _vp, _GP, _vp, _vp, _i, _i, _i, _i, _i, _f, _f],
+    "ssdseg_dwconv_parts": [_i, _i, _i, _i, _i, _ip],
+    "ssdseg_dwconv_fwd": [_vp, _VP, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "ssdseg_dwconv_bwd": [_vp, _VP, _vp, _GP, _vp, _vp, _i, _i, _i, _i, _i, _i, _i],
+    "ssdseg_pwconv_parts": [_i, _i, _ip],
+    "ssdseg_pwconv_fwd": [_vp, _VP, _i, _vp, _vp, _i, _i, _i, _i, _vp],
+    "ssdseg_pwconv_bwd_data": [_vp, _GP, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i],
+    "ssdseg_pwconv_bwd_weight": [_vp, _VP, _i, _GP, _i, _vp, _i, _i, _i],
+    "ssdseg_conv3x3_parts": [_i, _i, _i, _i, _ip],
+    "ssdseg_conv3x3_fwd": [_vp, _VP, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "ssdseg_conv3x3_bwd_data": [_vp, _GP, _vp, _vp, _i, _i, _i, _i, _i, _i, _i],
+    "ssdseg_conv3x3_bwd_weight": [_vp, _VP, _i, _GP, _vp, _i, _i, _i, _i, _i],
+    "ssdseg_bn_finalize": [_vp, _vp, _i, _i, _d, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i],
+    "ssdseg_channel_stats_parts": [_i, _i, _ip],
+    "ssdseg_channel_stats": [_vp, _vp, _i, _i, _i, _vp],
+    "ssdseg_bn_apply": [_vp, _VP, _i, _vp, _i, _vp, _i, _i, _i],
+    "ssdseg_bn_bwd_reduce": [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
+    "ssdseg_axpby": [_vp, _vp, _i, _vp, _i, _i, _i, _f, _f],
+    "ssdseg_gap_fwd": [_vp, _VP, _vp, _i, _i, _i],
+    "ssdseg_gap_bwd": [_vp, _vp, _vp, _i, _i, _i, _i],
+    "ssdseg_bilinear_fwd": [_vp, _VP, _i, _vp, _i, _i, _i, _i, _i, _i, _i],
+    "ssdseg_bilinear_bwd": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i],
+    "ssdseg_mask_head_fwd": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "ssdseg_mask_head_bwd": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _f, _vp],
+    "ssdseg_softmax_rows": [_vp, _VP, _vp, _i, _i],
+    "ssdseg_det_loss": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
+    "ssdseg_topk_mask": [_vp, _vp, _i, _i, _vp],
+    "ssdseg_dice_loss": [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp],
+    "ssdseg_encode_targets": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _f, C.POINTER(_f), _vp, _vp, _vp],
+    "ssdseg_decode_boxes": [_vp, _vp, _vp, _i, _i, C.POINTER(_f), _vp],
+    "ssdseg_combined_nms": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp],
+    "ssdseg_seg_suppress": [_vp, _vp, _i, _i, _vp, _i, _vp],
+    "ssdseg_adam_step": [_vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _i, _f],
+    "ssdseg_maxpool3x3s2_fwd": [_vp, _VP, _vp, _i, _i, _i, _i],
+    "ssdseg_maxpool3x3s2_bwd": [_vp, _VP, _vp, _vp, _i, _i, _i, _i],
+    "ssdseg_channel_shuffle": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i],
+}
+
+
+def library_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+
+
+def load_library():
+    """dlopen the in-tree shared library; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise SsdsegError(f"{path} not found: build it first (python -c 'import __graft_entry__ as g; g.build()' "
+                          f"or `make -C {os.path.dirname(path)}/../csrc`)")
+    lib = C.CDLL(path)
+    lib.ssdseg_last_error.restype = C.c_char_p
+    lib.ssdseg_last_error.argtypes = []
+    lib.ssdseg_version.restype = C.c_int
+    lib.ssdseg_version.argtypes = []
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            continue  # exported-symbol completeness is asserted by tests/test_cabi_symbols.py
+        fn.restype = C.c_int
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def declared_symbols() -> Sequence[str]:
+    return ["ssdseg_last_error", "ssdseg_version"] + list(_SIGNATURES)
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = load_library().ssdseg_last_error().decode("utf-8", "replace")
+        raise SsdsegError(f"{what} failed with code {rc}: {msg}")
+
+
+def _ptr(x) -> Optional[int]:
+    if x is None:
+        return None
+    if isinstance(x, DeviceBuffer):
+        return x.ptr
+    return int(x)
+
+
+class DeviceBuffer:
+    """A dense fp32/int32/uint8 array in HBM.  `view(offset_elems, shape)` aliases a sub-range (no copy)."""
+
+    def __init__(self, ctx: "Context", shape, dtype=np.float32, ptr: Optional[int] = None, owner=None):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.size = int(np.prod(self.shape)) if self.shape else 1
+        self.nbytes = self.size * self.dtype.itemsize
+        self._owner = owner          # keeps the parent allocation alive for views / borrowed memory
+        self._owns = ptr is None
+        if ptr is None:
+            out = C.c_void_p()
+            _check(ctx.lib.ssdseg_malloc(ctx.handle, max(self.nbytes, 4), C.byref(out)), "ssdseg_malloc")
+            self.ptr = out.value
+            ctx.allocated_bytes += self.nbytes
+        else:
+            self.ptr = int(ptr)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_owns", False) and self.ptr and self.ctx.handle:
+                self.ctx.lib.ssdseg_free(self.ctx.handle, C.c_void_p(self.ptr))
+                self.ctx.allocated_bytes -= self.nbytes
+        except Exception:
+            pass
+        self.ptr = None
+
+    def view(self, offset_elems: int, shape, dtype=None) -> "DeviceBuffer":
+        dt = self.dtype if dtype is None else np.dtype(dtype)
+        v = DeviceBuffer(self.ctx, shape, dt, ptr=self.ptr + int(offset_elems) * self.dtype.itemsize, owner=self)
+        assert int(offset_elems) * self.dtype.itemsize + v.nbytes <= self.nbytes, "view out of range"
+        return v
+
+    def reshape(self, shape) -> "DeviceBuffer":
+        v = DeviceBuffer(self.ctx, shape, self.dtype, ptr=self.ptr, owner=self)
+        assert v.size == self.size
+        return v
+
+    def upload(self, array) -> "DeviceBuffer":
+        a = np.ascontiguousarray(array, dtype=self.dtype)
+        assert a.size == self.size, f"upload size mismatch {a.shape} vs {self.shape}"
+        _check(self.ctx.lib.ssdseg_memcpy_h2d(self.ctx.handle, self.ptr, a.ctypes.data, self.nbytes), "ssdseg_memcpy_h2d")
+        return self
+
+    def download(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=self.dtype)
+        _check(self.ctx.lib.ssdseg_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, self.nbytes), "ssdseg_memcpy_d2h")
+        return out
+
+    def zero_(self) -> "DeviceBuffer":
+        _check(self.ctx.lib.ssdseg_memset(self.ctx.handle, self.ptr, 0, self.nbytes), "ssdseg_memset")
+        return self
+
+    def copy_from(self, other: "DeviceBuffer") -> "DeviceBuffer":
+        assert other.nbytes == self.nbytes
+        _check(self.ctx.lib.ssdseg_memcpy_d2d(self.ctx.handle, self.ptr, other.ptr, self.nbytes), "ssdseg_memcpy_d2d")
+        return self
+
+
+class Event:
+    def __init__(self, ctx: "Context"):
+        self.ctx = ctx
+        out = C.c_void_p()
+        _check(ctx.lib.ssdseg_event_create(ctx.handle, C.byref(out)), "ssdseg_event_create")
+        self.handle = out.value
+
+    def record(self):
+        _check(self.ctx.lib.ssdseg_event_record(self.ctx.handle, self.handle), "ssdseg_event_record")
+        return self
+
+    def elapsed_ms(self, stop: "Event") -> float:
+        ms = C.c_float()
+        _check(self.ctx.lib.ssdseg_event_elapsed_ms(self.ctx.handle, self.handle, stop.handle, C.byref(ms)), "ssdseg_event_elapsed_ms")
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            if self.handle and self.ctx.handle:
+                self.ctx.lib.ssdseg_event_destroy(self.ctx.handle, self.handle)
+        except Exception:
+            pass
+
+
+def view(x, scale=None, shift=None, act=ACT_NONE) -> ViewStruct:
+    return ViewStruct(_ptr(x), _ptr(scale), _ptr(shift), int(act), 0)
+
+
+def gview(g, y=None, scale=None, shift=None, k1=None, k0=None, act=ACT_NONE) -> GViewStruct:
+    return GViewStruct(_ptr(g), _ptr(y), _ptr(scale), _ptr(shift), _ptr(k1), _ptr(k0), int(act), 0)
+
+
+class Context:
+    """One (device, stream) execution context.  `stream` may be a raw hipStream_t (int) to borrow."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self.lib = load_library()
+        self.handle = None
+        self.allocated_bytes = 0
+        out = C.c_void_p()
+        _check(self.lib.ssdseg_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(out)), "ssdseg_ctx_create")
+        self.handle = out.value
+        self.device = int(device)
+
+    def close(self):
+        if self.handle:
+            self.lib.ssdseg_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        pass  # buffers may outlive us during interpreter shutdown; the process exit frees the device
+
+    # ---- memory
+    def empty(self, shape, dtype=np.float32) -> DeviceBuffer:
+        return DeviceBuffer(self, shape, dtype)
+
+    def zeros(self, shape, dtype=np.float32) -> DeviceBuffer:
+        return DeviceBuffer(self, shape, dtype).zero_()
+
+    def array(self, a, dtype=None) -> DeviceBuffer:
+        a = np.asarray(a)
+        dt = a.dtype if dtype is None else np.dtype(dtype)
+        return DeviceBuffer(self, a.shape, dt).upload(a)
+
+    def borrow(self, ptr: int, shape, dtype=np.float32, owner=None) -> DeviceBuffer:
+        return DeviceBuffer(self, shape, dtype, ptr=ptr, owner=owner)
+
+    def sync(self):
+        _check(self.lib.ssdseg_ctx_sync(self.handle), "ssdseg_ctx_sync")
+
+    def reserve(self, nbytes: int):
+        _check(self.lib.ssdseg_ctx_reserve(self.handle, int(nbytes)), "ssdseg_ctx_reserve")
+
+    def device_name(self) -> str:
+        buf = C.create_string_buffer(256)
+        _check(self.lib.ssdseg_ctx_device_name(self.handle, buf, 256), "ssdseg_ctx_device_name")
+        return buf.value.decode()
+
+    def event(self) -> Event:
+        return Event(self)
+
+    # ---- hipGraph capture
+    def graph_begin(self):
+        _check(self.lib.ssdseg_graph_begin(self.handle), "ssdseg_graph_begin")
+
+    def graph_end(self) -> int:
+        out = C.c_void_p()
+        _check(self.lib.ssdseg_graph_end(self.handle, C.byref(out)), "ssdseg_graph_end")
+        return out.value
+
+    def graph_launch(self, g: int):
+        _check(self.lib.ssdseg_graph_launch(self.handle, g), "ssdseg_graph_launch")
+
+    def graph_destroy(self, g: int):
+        _check(self.lib.ssdseg_graph_destroy(self.handle, g), "ssdseg_graph_destroy")
+
+    # ---- generic call: ctx.call("ssdseg_pwconv_fwd", view, ldx, w, y, ...) with DeviceBuffer/None/int/float args
+    def call(self, name: str, *args):
+        fn = getattr(self.lib, name)
+        conv = []
+        for a in args:
+            if isinstance(a, DeviceBuffer):
+                conv.append(C.c_void_p(a.ptr))
+            elif isinstance(a, (ViewStruct, GViewStruct)):
+                conv.append(C.byref(a))
+            else:
+                conv.append(a)
+        _check(fn(self.handle, *conv), name)
+
+    def parts(self, name: str, *dims) -> int:
+        out = C.c_int()
+        _check(getattr(self.lib, name)(*[int(d) for d in dims], C.byref(out)), name)
+        return out.value
+
+
+def device_count() -> int:
+    n = C.c_int()
+    _check(load_library().ssdseg_device_count(C.byref(n)), "ssdseg_device_count")
+    return n.value
+
+
+def same_pad(size: int, k: int, s: int, d: int) -> Tuple[int, int, int]:
+    """TF SAME geometry -> (out, pad_before, pad_after)  (SURVEY.md App. B.1)."""
+    out = -(-size // s)
+    keff = (k - 1) * d + 1
+    total = max((out - 1) * s + keff - size, 0)
+    return out, total // 2, total - total // 2

@@ -1,0 +1,38 @@
+"""pytest configuration: `gpu` marker, import path of the product package and the oracle, shared fixtures."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(REPO, "multi-task-learning-object-detection-semantic-segmentation_amd")
+for p in (REPO, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    """One HIP context for the whole GPU session (fails loudly if the library or the GPU is missing)."""
+    from ssdseglib import _hip
+    c = _hip.Context(0)
+    yield c
+    c.sync()
+    c.close()
+
+
+@pytest.fixture()
+def rng():
+    return np.random.default_rng(1993)

@@ -1,0 +1,253 @@
+"""GPU parity: HIP conv / BN kernels (through the C-ABI) vs the NumPy oracle on the same seeded inputs.
+
+Tolerance: north_star asks 1e-3 relative for conv/loss floats; single ops are held to 2e-5 of the tensor's
+max magnitude (fp32 accumulation-order noise), reductions over millions of elements to 1e-4.
+"""
+import numpy as np
+import pytest
+
+from oracle import np_ops as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def make_view_inputs(rng, shape, act):
+    """raw tensor + per-channel affine such that the activation clips a good share of the values"""
+    c = shape[-1]
+    x = rng.normal(0, 2.0, shape).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, c).astype(np.float32)
+    shift = rng.uniform(-1, 3, c).astype(np.float32)
+    a = O.act_fwd(x * scale + shift, act)
+    return x, scale, shift, a
+
+
+def make_gview_inputs(rng, shape, act):
+    """g, raw y, BN-backward coefficients -> dy exactly as the kernels must form it"""
+    c = shape[-1]
+    g = rng.normal(0, 1, shape).astype(np.float32)
+    y = rng.normal(0, 2, shape).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, c).astype(np.float32)
+    shift = rng.uniform(-1, 3, c).astype(np.float32)
+    k1 = rng.normal(0, 0.1, c).astype(np.float32)
+    k0 = rng.normal(0, 0.1, c).astype(np.float32)
+    dy = scale * O.act_mask(y * scale + shift, act) * g + k1 * y + k0
+    return g, y, scale, shift, k1, k0, dy.astype(np.float32)
+
+
+DW_CASES = [
+    # n, h, w, c, stride, dilation
+    (2, 15, 20, 32, 1, 1),
+    (2, 15, 20, 32, 2, 1),     # 15 -> 8 pads (1,1); 20 -> 10 pads (0,1)
+    (1, 30, 40, 144, 2, 1),    # 36 channel vectors
+    (2, 8, 10, 960, 1, 1),     # 240 channel vectors
+    (1, 9, 7, 8, 2, 1),        # odd x odd, pads (1,1)/(1,1)
+    (1, 10, 7, 8, 2, 1),       # pads (0,1)/(1,1)
+    (1, 9, 8, 8, 2, 1),        # pads (1,1)/(0,1)
+    (2, 30, 40, 64, 1, 3),     # atrous
+    (1, 30, 40, 32, 1, 12),
+    (1, 5, 6, 1284, 1, 1),     # > 256 channel vectors (grid.y = 2)
+    (1, 1, 1, 4, 1, 1),
+]
+
+
+@pytest.mark.parametrize("n,h,w,c,s,d", DW_CASES)
+@pytest.mark.parametrize("act", [O.ACT_RELU6, O.ACT_NONE])
+def test_dwconv_fwd_bwd(ctx, rng, n, h, w, c, s, d, act):
+    from ssdseglib import _hip as H
+    x, sc, sh, a = make_view_inputs(rng, (n, h, w, c), act)
+    wgt = rng.normal(0, 0.3, (3, 3, c)).astype(np.float32)
+    y_ref = O.dwconv_fwd(a, wgt, s, d)
+    ho, wo = y_ref.shape[1:3]
+    dx_, dsc, dsh = ctx.array(x), ctx.array(sc), ctx.array(sh)
+    dw_ = ctx.array(wgt)
+    dy_ = ctx.empty(y_ref.shape)
+    nparts = ctx.parts("ssdseg_dwconv_parts", n, h, w, c, s)
+    stats = ctx.empty((nparts, 2, c))
+    ctx.call("ssdseg_dwconv_fwd", H.view(dx_, dsc, dsh, act), dw_, dy_, n, h, w, c, s, d, stats)
+    y = dy_.download()
+    assert rel_err(y, y_ref) < 2e-5
+    st = stats.download().astype(np.float64).sum(axis=0)
+    assert rel_err(st[0], y_ref.sum(axis=(0, 1, 2), dtype=np.float64)) < 1e-4 or np.abs(st[0] - y_ref.sum(axis=(0, 1, 2))).max() < 1e-3
+    assert rel_err(st[1], (y_ref.astype(np.float64) ** 2).sum(axis=(0, 1, 2))) < 1e-4
+
+    # backward: dy formed from a gradient view
+    g, yraw, gs, gt, k1, k0, dy = make_gview_inputs(rng, y_ref.shape, O.ACT_RELU6)
+    dx_ref, dw_ref = O.dwconv_bwd(a, wgt, dy, s, d)
+    bufs = [ctx.array(v) for v in (g, yraw, gs, gt, k1, k0)]
+    gv = H.gview(*bufs, act=O.ACT_RELU6)
+    ddx = ctx.empty(x.shape)
+    ddw = ctx.empty(wgt.shape)
+    ctx.call("ssdseg_dwconv_bwd", H.view(dx_, dsc, dsh, act), dw_, gv, ddx, ddw, n, h, w, c, s, d, 0)
+    assert rel_err(ddx.download(), dx_ref) < 2e-5
+    assert rel_err(ddw.download(), dw_ref) < 1e-4
+    # accumulate into an existing gradient (fan-out taps)
+    base = rng.normal(0, 1, x.shape).astype(np.float32)
+    ddx.upload(base)
+    ctx.call("ssdseg_dwconv_bwd", H.view(dx_, dsc, dsh, act), dw_, gv, ddx, ddw, n, h, w, c, s, d, 1)
+    assert rel_err(ddx.download(), dx_ref + base) < 2e-5
+    # identity gradient view
+    gid = H.gview(bufs[0])
+    ctx.call("ssdseg_dwconv_bwd", H.view(dx_, dsc, dsh, act), dw_, gid, ddx, ddw, n, h, w, c, s, d, 0)
+    dx_ref2, dw_ref2 = O.dwconv_bwd(a, wgt, g, s, d)
+    assert rel_err(ddx.download(), dx_ref2) < 2e-5
+    assert rel_err(ddw.download(), dw_ref2) < 1e-4
+
+
+PW_CASES = [
+    # m, k, n
+    (640, 16, 96),
+    (1000, 96, 24),      # row tail, n < 32
+    (300, 24, 144),      # n = 4.5 tiles
+    (257, 144, 32),
+    (2048, 576, 160),
+    (130, 960, 320),
+    (512, 1280, 256),
+    (77, 360, 24),
+    (4096, 32, 16),
+    (100, 8, 4),
+]
+
+
+@pytest.mark.parametrize("m,k,n", PW_CASES)
+def test_pwconv_fwd_bwd(ctx, rng, m, k, n):
+    from ssdseglib import _hip as H
+    act = O.ACT_RELU6
+    x, sc, sh, a = make_view_inputs(rng, (m, k), act)
+    wgt = (rng.normal(0, 1, (k, n)) / np.sqrt(k)).astype(np.float32)
+    y_ref = a.astype(np.float64) @ wgt.astype(np.float64)
+    dx_, dsc, dsh, dw_ = ctx.array(x), ctx.array(sc), ctx.array(sh), ctx.array(wgt)
+    dy_ = ctx.empty((m, n))
+    nparts = ctx.parts("ssdseg_pwconv_parts", m, n)
+    stats = ctx.empty((nparts, 2, n))
+    ctx.call("ssdseg_pwconv_fwd", H.view(dx_, dsc, dsh, act), k, dw_, dy_, n, m, k, n, stats)
+    y = dy_.download()
+    assert rel_err(y, y_ref) < 2e-5
+    st = stats.download().astype(np.float64).sum(axis=0)
+    assert np.abs(st[0] - y_ref.sum(axis=0)).max() < 1e-4 * max(1.0, np.abs(y_ref).sum(axis=0).max())
+    assert rel_err(st[1], (y_ref ** 2).sum(axis=0)) < 1e-4
+    # identity view, no stats
+    ctx.call("ssdseg_pwconv_fwd", H.view(dx_), k, dw_, dy_, n, m, k, n, None)
+    assert rel_err(dy_.download(), x.astype(np.float64) @ wgt.astype(np.float64)) < 2e-5
+
+    g, yraw, gs, gt, k1, k0, dy = make_gview_inputs(rng, (m, n), O.ACT_RELU6)
+    bufs = [ctx.array(v) for v in (g, yraw, gs, gt, k1, k0)]
+    gv = H.gview(*bufs, act=O.ACT_RELU6)
+    dxg = ctx.empty((m, k))
+    ctx.call("ssdseg_pwconv_bwd_data", gv, n, dw_, dxg, k, m, k, n, None, 0, 0)
+    dx_ref = dy.astype(np.float64) @ wgt.astype(np.float64).T
+    assert rel_err(dxg.download(), dx_ref) < 2e-5
+    res = rng.normal(0, 1, (m, k)).astype(np.float32)
+    dres = ctx.array(res)
+    base = rng.normal(0, 1, (m, k)).astype(np.float32)
+    dxg.upload(base)
+    ctx.call("ssdseg_pwconv_bwd_data", gv, n, dw_, dxg, k, m, k, n, dres, k, 1)
+    assert rel_err(dxg.download(), dx_ref + res + base) < 2e-5
+
+    dwg = ctx.empty((k, n))
+    ctx.call("ssdseg_pwconv_bwd_weight", H.view(dx_, dsc, dsh, act), k, gv, n, dwg, m, k, n)
+    dw_ref = a.astype(np.float64).T @ dy.astype(np.float64)
+    assert rel_err(dwg.download(), dw_ref) < 5e-5
+
+
+def test_pwconv_strided_concat_slice(ctx, rng):
+    """ldx/ldy: read a channel slice of a wider buffer and write into a slice of a concat buffer (K10)."""
+    from ssdseglib import _hip as H
+    m, k, n, ldx, ldy = 200, 48, 64, 80, 304
+    xw = rng.normal(0, 1, (m, ldx)).astype(np.float32)
+    wgt = rng.normal(0, 0.2, (k, n)).astype(np.float32)
+    big = ctx.zeros((m, ldy))
+    dxw = ctx.array(xw)
+    ctx.call("ssdseg_pwconv_fwd", H.view(dxw.view(16, (m, k))), ldx, ctx.array(wgt), big.view(240, (m, n)), ldy, m, k, n, None)
+    out = big.download()
+    assert rel_err(out[:, 240:304], xw[:, 16:64].astype(np.float64) @ wgt) < 2e-5
+    assert np.all(out[:, :240] == 0)
+
+
+@pytest.mark.parametrize("m,c,parts", [(5000, 96, 700), (64, 24, 3), (100000, 16, 19200 // 8)])
+def test_bn_finalize_apply_bwd(ctx, rng, m, c, parts):
+    from ssdseglib import _hip as H
+    y = rng.normal(0.5, 2.0, (m, c)).astype(np.float32)
+    gamma = rng.uniform(0.5, 1.5, c).astype(np.float32)
+    beta = rng.normal(0, 0.5, c).astype(np.float32)
+    mm0 = rng.normal(0, 1, c).astype(np.float32)
+    mv0 = rng.uniform(0.5, 2, c).astype(np.float32)
+    z_ref, cache = O.bn_train_fwd(y, gamma, beta)
+    mm_ref, mv_ref = O.bn_moving_update(mm0, mv0, cache)
+    # channel stats kernel -> partials; also synthesise a many-rows partial table to hit the fold path
+    dy_ = ctx.array(y)
+    np_ = ctx.parts("ssdseg_channel_stats_parts", m, c)
+    st = ctx.empty((np_, 2, c))
+    ctx.call("ssdseg_channel_stats", dy_, c, m, c, st)
+    tot = st.download().astype(np.float64).sum(axis=0)
+    assert rel_err(tot[0], y.sum(axis=0, dtype=np.float64)) < 1e-5
+    # spread the true sums over `parts` rows
+    idx = np.arange(m) % parts
+    tab = np.zeros((parts, 2, c), np.float64)
+    np.add.at(tab[:, 0], idx, y.astype(np.float64))
+    np.add.at(tab[:, 1], idx, y.astype(np.float64) ** 2)
+    dtab = ctx.array(tab.astype(np.float32))
+    bufs = {k: ctx.array(v) for k, v in dict(gamma=gamma, beta=beta, mm=mm0, mv=mv0).items()}
+    mean, invstd, scale, shift = (ctx.empty(c) for _ in range(4))
+    ctx.call("ssdseg_bn_finalize", dtab, parts, c, float(m), bufs["gamma"], bufs["beta"], 1e-3, 0.99, bufs["mm"], bufs["mv"],
+             mean, invstd, scale, shift, 1)
+    assert rel_err(mean.download(), cache["mean"]) < 1e-5
+    assert rel_err(invstd.download(), cache["invstd"]) < 1e-5
+    assert rel_err(scale.download(), cache["scale"]) < 1e-5
+    assert np.abs(shift.download() - cache["shift"]).max() < 1e-5
+    assert rel_err(bufs["mm"].download(), mm_ref) < 1e-5
+    assert rel_err(bufs["mv"].download(), mv_ref) < 1e-5
+    # inference affine from the moving statistics
+    s2, t2 = ctx.empty(c), ctx.empty(c)
+    ctx.call("ssdseg_bn_finalize", None, 0, c, 0.0, bufs["gamma"], bufs["beta"], 1e-3, 0.99, bufs["mm"], bufs["mv"], None, None, s2, t2, 0)
+    s_ref, t_ref = O.bn_infer_affine(gamma, beta, bufs["mm"].download(), bufs["mv"].download())
+    assert rel_err(s2.download(), s_ref) < 1e-5 and np.abs(t2.download() - t_ref).max() < 1e-5
+
+    # apply (+ residual)
+    res = rng.normal(0, 1, (m, c)).astype(np.float32)
+    out = ctx.empty((m, c))
+    ctx.call("ssdseg_bn_apply", H.view(dy_, scale, shift, O.ACT_RELU6), c, ctx.array(res), c, out, c, m, c)
+    assert np.abs(out.download() - (O.act_fwd(z_ref, O.ACT_RELU6) + res)).max() < 2e-5
+
+    # backward: reduce -> coefficients -> dy through the gradient view formula
+    g = rng.normal(0, 1, (m, c)).astype(np.float32)
+    dz = g * O.act_mask(z_ref, O.ACT_RELU6)
+    dy_ref, dgamma_ref, dbeta_ref = O.bn_train_bwd(dz, y, gamma, cache)
+    dgamma, dbeta, k1, k0 = (ctx.empty(c) for _ in range(4))
+    ctx.call("ssdseg_bn_bwd_reduce", ctx.array(g), c, dy_, c, m, c, scale, shift, mean, invstd, O.ACT_RELU6, dgamma, dbeta, k1, k0)
+    assert rel_err(dgamma.download(), dgamma_ref) < 1e-4
+    assert rel_err(dbeta.download(), dbeta_ref) < 1e-4
+    sc = scale.download(); sh = shift.download()
+    dy = sc * O.act_mask(y * sc + sh, O.ACT_RELU6) * g + k1.download() * y + k0.download()
+    assert np.abs(dy - dy_ref).max() < 1e-4 * max(1.0, np.abs(dy_ref).max())
+
+
+@pytest.mark.parametrize("n,h,w,cout,bias", [(2, 48, 64, 32, False), (1, 15, 21, 24, True), (3, 480, 640, 32, False)])
+def test_stem_conv(ctx, rng, n, h, w, cout, bias):
+    from ssdseglib import _hip as H
+    x = rng.integers(0, 256, (n, h, w, 3)).astype(np.float32)
+    wgt = rng.normal(0, 0.3, (3, 3, 3, cout)).astype(np.float32)
+    b = rng.normal(0, 0.3, cout).astype(np.float32) if bias else None
+    xr = O.rescale(x)
+    y_ref = O.conv2d_fwd(xr, wgt, 2, 1, b)
+    dx_, dw_ = ctx.array(x), ctx.array(wgt)
+    db_ = ctx.array(b) if bias else None
+    y = ctx.empty(y_ref.shape)
+    nparts = ctx.parts("ssdseg_stem_conv_parts", n, h, w, cout)
+    stats = ctx.empty((nparts, 2, cout))
+    ctx.call("ssdseg_stem_conv_fwd", dx_, dw_, db_, y, n, h, w, 3, cout, 1.0 / 127.5, -1.0, stats)
+    assert rel_err(y.download(), y_ref) < 2e-5
+    st = stats.download().astype(np.float64).sum(axis=0)
+    assert rel_err(st[1], (y_ref.astype(np.float64) ** 2).sum(axis=(0, 1, 2))) < 1e-4
+    g, yraw, gs, gt, k1, k0, dy = make_gview_inputs(rng, y_ref.shape, O.ACT_RELU6)
+    bufs = [ctx.array(v) for v in (g, yraw, gs, gt, k1, k0)]
+    dwg = ctx.empty(wgt.shape)
+    dbg = ctx.empty(cout)
+    ctx.call("ssdseg_stem_conv_bwd_weight", dx_, H.gview(*bufs, act=O.ACT_RELU6), dwg, dbg, n, h, w, 3, cout, 1.0 / 127.5, -1.0)
+    _, dw_ref, db_ref = O.conv2d_bwd(xr.astype(np.float64), wgt.astype(np.float64), dy.astype(np.float64), 2, 1)
+    assert rel_err(dwg.download(), dw_ref) < 1e-4
+    assert rel_err(dbg.download(), db_ref) < 1e-4
