@@ -167,11 +167,12 @@ int ssdseg_bn_finalize(ssdseg_ctx* ctx, const float* stats, int nparts, int c, d
  * not produced by one of the conv kernels, e.g. the GAP branch) */
 int ssdseg_channel_stats_parts(int m, int c, int* nparts_host);
 int ssdseg_channel_stats(ssdseg_ctx* ctx, const float* x, int ld, int m, int c, float* stats);
-/* materialise out = act(scale*x + shift) (+ residual): Add (models.py:162,593), taps, concat slices */
-int ssdseg_bn_apply(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const float* residual, int ldr, float* out,
+/* materialise out = view(in) (+ view(residual)): Add (models.py:162,593), taps, concat slices; residual may be NULL */
+int ssdseg_bn_apply(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssdseg_view* residual, int ldr, float* out,
                     int ldo, int m, int c);
 /* BN backward reductions: dbeta = sum mask*g, dgamma = sum mask*g*xhat over [m][c]; writes
- * dgamma, dbeta (added into the trainable-gradient buffers) and the gview coefficients k1, k0. */
+ * dgamma, dbeta (each BatchNormalization has one use, so they are stored, not accumulated) and the gview
+ * coefficients k1, k0. */
 int ssdseg_bn_bwd_reduce(ssdseg_ctx* ctx, const float* g, int ldg, const float* y, int ldy, int m, int c,
                          const float* scale, const float* shift, const float* mean, const float* invstd, int act,
                          float* dgamma, float* dbeta, float* k1, float* k0);

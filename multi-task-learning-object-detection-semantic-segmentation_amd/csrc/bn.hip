@@ -145,16 +145,21 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int npart
 }
 
 __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift, int act,
-                                int ldx, const float* __restrict__ residual, int ldr, float* __restrict__ out, int ldo, long long m, int cv) {
+                                int ldx, const float* __restrict__ rx, const float* __restrict__ rscale, const float* __restrict__ rshift,
+                                int ract, int ldr, float* __restrict__ out, int ldo, long long m, int cv) {
     const long long total = m * cv;
+    const bool aff = scale != nullptr, raff = rscale != nullptr;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long r = i / cv;
         const int c0 = (int)(i % cv) * 4;
         float4 s = f4(0.f), t = f4(0.f);
-        const bool aff = scale != nullptr;
         if (aff) { s = ld4(scale + c0); t = ld4(shift + c0); }
         float4 v = view_apply4(ld4(x + r * ldx + c0), s, t, aff, act);
-        if (residual) add4(v, ld4(residual + r * ldr + c0));
+        if (rx) {
+            float4 rs = f4(0.f), rt = f4(0.f);
+            if (raff) { rs = ld4(rscale + c0); rt = ld4(rshift + c0); }
+            add4(v, view_apply4(ld4(rx + r * ldr + c0), rs, rt, raff, ract));
+        }
         st4(out + r * ldo + c0, v);
     }
 }
@@ -263,11 +268,12 @@ int ssdseg_channel_stats(ssdseg_ctx* ctx, const float* x, int ld, int m, int c, 
     return 0;
 }
 
-int ssdseg_bn_apply(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const float* residual, int ldr, float* out, int ldo,
+int ssdseg_bn_apply(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssdseg_view* residual, int ldr, float* out, int ldo,
                     int m, int c) {
     SSDSEG_ARG(ctx != nullptr, 1);
     SSDSEG_ARG(in != nullptr && in->x != nullptr && ((in->scale == nullptr) == (in->shift == nullptr)), 2);
     SSDSEG_ARG(ldx >= c && ldx % 4 == 0, 3);
+    SSDSEG_ARG(residual == nullptr || (residual->x != nullptr && ((residual->scale == nullptr) == (residual->shift == nullptr))), 4);
     SSDSEG_ARG(residual == nullptr || (ldr >= c && ldr % 4 == 0), 5);
     SSDSEG_ARG(out != nullptr, 6);
     SSDSEG_ARG(ldo >= c && ldo % 4 == 0, 7);
@@ -275,7 +281,8 @@ int ssdseg_bn_apply(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const float
     SSDSEG_ARG(c > 0 && c % 4 == 0, 9);
     const long long total = (long long)m * (c / 4);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(total)), dim3(256), 0, ctx->stream, in->x, in->scale, in->shift, in->act, ldx,
-                       residual, ldr, out, ldo, (long long)m, c / 4);
+                       residual ? residual->x : nullptr, residual ? residual->scale : nullptr, residual ? residual->shift : nullptr,
+                       residual ? residual->act : 0, ldr, out, ldo, (long long)m, c / 4);
     SSDSEG_LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,841 @@
+"""Lowers a `_graph.Model` to a static list of fused HIP launches (forward list, reversed backward list).
+
+This is the stand-in for the part of Keras the reference relies on (`Model.__call__/fit/predict`, GradientTape,
+Adam -- third-party), written around the MI355X design:
+
+  * conv -> BatchNormalization(train) -> ReLU6 is never three passes: the conv kernel writes the RAW tensor once
+    plus per-block (sum, sumsq); `bn_finalize` makes per-channel (scale, shift); every consumer applies
+    act(scale*y+shift) while loading (`Val` below is that lazy view).  Backward mirrors it: one reduction pass per
+    BN gives (k1, k0) and the producing conv's backward kernels form dY on load (gradient view).
+  * Concatenate over channels is a write offset (producers write straight into their slice of the concat
+    buffer, `ld` = total channels), Reshape/Split are metadata.
+  * everything stays resident in HBM (288 GB): no recomputation, no activation re-use planning.
+  * the launch list is static, so a whole step can be captured in a hipGraph.
+
+Manual backward replaces autodiff: every op below carries its own `bwd`.  Gradient fan-in order is the fixed
+reverse launch order (deterministic).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _graph as K
+from . import _hip as H
+from . import layers as L
+
+ACT_NONE, ACT_RELU, ACT_RELU6, ACT_ZERO = H.ACT_NONE, H.ACT_RELU, H.ACT_RELU6, H.ACT_ZERO
+
+
+def _act_of(relu: K.ReLU) -> int:
+    if relu.max_value is None:
+        return ACT_RELU
+    if relu.max_value == 0.0:
+        return ACT_ZERO          # quirk Q1: Keras clips to [0, 0]
+    if relu.max_value == 6.0:
+        return ACT_RELU6
+    raise NotImplementedError(f"ReLU(max_value={relu.max_value}) is not used by ssdseglib")
+
+
+class Store:
+    """A tensor region resident in HBM: rows m = n*h*w, c channels, row stride ld (>= c for concat slices)."""
+
+    def __init__(self, eng: "Engine", n, h, w, c, name, buf: Optional[H.DeviceBuffer] = None, ld: Optional[int] = None,
+                 parent: Optional["Store"] = None, coff: int = 0, need_grad: bool = True):
+        self.eng, self.n, self.h, self.w, self.c, self.name = eng, n, h, w, c, name
+        self.m = n * h * w
+        self.ld = c if ld is None else ld
+        self.parent, self.coff = parent, coff
+        self.buf = buf if buf is not None else eng.ctx.empty((self.m, self.ld))
+        self.need_grad = need_grad
+        self._grad: Optional[H.DeviceBuffer] = None
+        self.gwritten = False
+        self.stats: Optional[H.DeviceBuffer] = None   # per-block (sum, sumsq) partials from the producing conv
+        self.nparts = 0
+
+    def slice(self, coff: int, c: int, name: str) -> "Store":
+        assert coff + c <= self.c
+        return Store(self.eng, self.n, self.h, self.w, c, name, buf=self.buf.view(coff, (self.m * self.ld - coff,)), ld=self.ld,
+                     parent=self, coff=coff, need_grad=self.need_grad)
+
+    @property
+    def grad(self) -> H.DeviceBuffer:
+        if self._grad is None:
+            if self.parent is not None:
+                pg = self.parent.grad
+                self._grad = pg.view(self.coff, (self.m * self.ld - self.coff,))
+            else:
+                self._grad = self.eng.ctx.zeros((self.m, self.ld))
+        return self._grad
+
+    def grad_slot(self) -> Tuple[H.DeviceBuffer, int]:
+        """(gradient buffer, accumulate flag) for a consumer's backward; first writer overwrites."""
+        acc = 1 if (self.gwritten or (self.parent is not None and self.parent.gwritten)) else 0
+        self.gwritten = True
+        return self.grad, acc
+
+
+class BNRec:
+    """Device state of one BatchNormalization layer."""
+
+    def __init__(self, eng, layer: K.BatchNormalization, c: int, scale=None, shift=None):
+        ctx = eng.ctx
+        self.layer, self.c = layer, c
+        self.gamma, self.beta = eng.param_view(layer, "gamma"), eng.param_view(layer, "beta")
+        self.dgamma, self.dbeta = eng.grad_view(layer, "gamma"), eng.grad_view(layer, "beta")
+        self.moving_mean, self.moving_var = eng.state_view(layer, "moving_mean"), eng.state_view(layer, "moving_variance")
+        self.scale = scale if scale is not None else ctx.empty(c)
+        self.shift = shift if shift is not None else ctx.empty(c)
+        self.mean, self.invstd, self.k1, self.k0 = ctx.empty(c), ctx.empty(c), ctx.empty(c), ctx.empty(c)
+        self.act = ACT_NONE
+
+
+class Val:
+    """Lowered value of a symbolic tensor: a = act(scale * store + shift) (scale None -> act(store))."""
+
+    def __init__(self, store: Store, scale=None, shift=None, act=ACT_NONE, bn: Optional[BNRec] = None, **meta):
+        self.store, self.scale, self.shift, self.act, self.bn = store, scale, shift, act, bn
+        self.meta = meta
+
+    def view(self) -> H.ViewStruct:
+        return H.view(self.store.buf, self.scale, self.shift, self.act)
+
+    def gview(self) -> H.GViewStruct:
+        """gradient view of this value's RAW store for the backward of the op that produced the store"""
+        s = self.store
+        if self.bn is not None:
+            b = self.bn
+            return H.gview(s.grad, s.buf, b.scale, b.shift, b.k1, b.k0, b.act)
+        return H.gview(s.grad)
+
+
+# ====================================================================================================== ops
+class Op:
+    name = ""
+
+    def fwd(self):
+        pass
+
+    def bwd(self):
+        pass
+
+
+class StemOp(Op):
+    def __init__(self, eng, layer: K.Conv2D, image: Store, rescale, out: Store):
+        self.e, self.layer, self.image, self.rescale, self.out = eng, layer, image, rescale, out
+        self.name = layer.name
+        self.w = eng.param_view(layer, "kernel")
+        self.b = eng.param_view(layer, "bias") if layer.use_bias else None
+        self.dw = eng.grad_view(layer, "kernel")
+        self.db = eng.grad_view(layer, "bias") if layer.use_bias else None
+        if eng.training:
+            out.nparts = eng.ctx.parts("ssdseg_stem_conv_parts", image.n, image.h, image.w, out.c)
+            out.stats = eng.ctx.empty((out.nparts, 2, out.c))
+        self.out_val: Optional[Val] = None
+
+    def fwd(self):
+        i = self.image
+        self.e.ctx.call("ssdseg_stem_conv_fwd", i.buf, self.w, self.b, self.out.buf, i.n, i.h, i.w, i.c, self.out.c,
+                        self.rescale[0], self.rescale[1], self.out.stats)
+
+    def bwd(self):
+        i = self.image
+        self.e.ctx.call("ssdseg_stem_conv_bwd_weight", i.buf, self.out_val.gview(), self.dw, self.db, i.n, i.h, i.w, i.c, self.out.c,
+                        self.rescale[0], self.rescale[1])
+
+
+class DwOp(Op):
+    def __init__(self, eng, layer, wname: str, inp: Val, out: Store, stride: int, dilation: int):
+        self.e, self.layer, self.inp, self.out, self.stride, self.dilation = eng, layer, inp, out, stride, dilation
+        self.name = layer.name + ":dw"
+        self.w, self.dw = eng.param_view(layer, wname), eng.grad_view(layer, wname)
+        s = inp.store
+        if eng.training:
+            out.nparts = eng.ctx.parts("ssdseg_dwconv_parts", s.n, s.h, s.w, s.c, stride)
+            out.stats = eng.ctx.empty((out.nparts, 2, out.c))
+        assert s.ld == s.c and out.ld == out.c, "depthwise kernels work on dense (non-sliced) tensors"
+        self.out_val: Optional[Val] = None
+
+    def fwd(self):
+        s = self.inp.store
+        self.e.ctx.call("ssdseg_dwconv_fwd", self.inp.view(), self.w, self.out.buf, s.n, s.h, s.w, s.c, self.stride, self.dilation,
+                        self.out.stats)
+
+    def bwd(self):
+        s = self.inp.store
+        dx, acc = (s.grad_slot() if s.need_grad else (None, 0))
+        self.e.ctx.call("ssdseg_dwconv_bwd", self.inp.view(), self.w, self.out_val.gview(), dx, self.dw, s.n, s.h, s.w, s.c, self.stride,
+                        self.dilation, acc)
+
+
+class PwOp(Op):
+    def __init__(self, eng, layer, wname: str, inp: Val, out: Store):
+        self.e, self.layer, self.inp, self.out = eng, layer, inp, out
+        self.name = layer.name + ":pw"
+        self.w, self.dw = eng.param_view(layer, wname), eng.grad_view(layer, wname)
+        self.m, self.k, self.n = inp.store.m, inp.store.c, out.c
+        if eng.training:
+            out.nparts = eng.ctx.parts("ssdseg_pwconv_parts", self.m, self.n)
+            out.stats = eng.ctx.empty((out.nparts, 2, self.n))
+        self.out_val: Optional[Val] = None
+
+    def fwd(self):
+        self.e.ctx.call("ssdseg_pwconv_fwd", self.inp.view(), self.inp.store.ld, self.w, self.out.buf, self.out.ld, self.m, self.k, self.n,
+                        self.out.stats)
+
+    def bwd(self):
+        s = self.inp.store
+        gv = self.out_val.gview()
+        self.e.ctx.call("ssdseg_pwconv_bwd_weight", self.inp.view(), s.ld, gv, self.out.ld, self.dw, self.m, self.k, self.n)
+        if s.need_grad:
+            dx, acc = s.grad_slot()
+            self.e.ctx.call("ssdseg_pwconv_bwd_data", gv, self.out.ld, self.w, dx, s.ld, self.m, self.k, self.n, None, 0, acc)
+
+
+class Conv3Op(Op):
+    def __init__(self, eng, layer, inp: Val, out: Store):
+        self.e, self.layer, self.inp, self.out = eng, layer, inp, out
+        self.name = layer.name + ":conv3x3"
+        self.w, self.dw = eng.param_view(layer, "kernel"), eng.grad_view(layer, "kernel")
+        s = inp.store
+        if eng.training:
+            out.nparts = eng.ctx.parts("ssdseg_conv3x3_parts", s.n, s.h, s.w, out.c)
+            out.stats = eng.ctx.empty((out.nparts, 2, out.c))
+        assert out.ld == out.c
+        self.out_val: Optional[Val] = None
+
+    def fwd(self):
+        s = self.inp.store
+        self.e.ctx.call("ssdseg_conv3x3_fwd", self.inp.view(), s.ld, self.w, self.out.buf, s.n, s.h, s.w, s.c, self.out.c, self.out.stats)
+
+    def bwd(self):
+        s = self.inp.store
+        gv = self.out_val.gview()
+        self.e.ctx.call("ssdseg_conv3x3_bwd_weight", self.inp.view(), s.ld, gv, self.dw, s.n, s.h, s.w, s.c, self.out.c)
+        if s.need_grad:
+            dx, acc = s.grad_slot()
+            self.e.ctx.call("ssdseg_conv3x3_bwd_data", gv, self.w, dx, s.ld, s.n, s.h, s.w, s.c, self.out.c, acc)
+
+
+class BnOp(Op):
+    def __init__(self, eng, rec: BNRec, store: Store):
+        self.e, self.rec, self.store = eng, rec, store
+        self.name = rec.layer.name
+
+    def fwd(self):
+        r, s = self.rec, self.store
+        l = r.layer
+        if self.e.training:
+            assert s.stats is not None, f"{self.name}: producer of {s.name} did not emit batch statistics"
+            self.e.ctx.call("ssdseg_bn_finalize", s.stats, s.nparts, r.c, float(s.m), r.gamma, r.beta, l.epsilon, l.momentum, r.moving_mean,
+                            r.moving_var, r.mean, r.invstd, r.scale, r.shift, 1)
+        else:
+            self.e.ctx.call("ssdseg_bn_finalize", None, 0, r.c, 0.0, r.gamma, r.beta, l.epsilon, l.momentum, r.moving_mean, r.moving_var,
+                            None, None, r.scale, r.shift, 0)
+
+    def bwd(self):
+        r, s = self.rec, self.store
+        self.e.ctx.call("ssdseg_bn_bwd_reduce", s.grad, s.ld, s.buf, s.ld, s.m, r.c, r.scale, r.shift, r.mean, r.invstd, r.act, r.dgamma,
+                        r.dbeta, r.k1, r.k0)
+
+
+class ChannelStatsOp(Op):
+    """batch statistics for a raw tensor whose producer has no fused stats epilogue"""
+
+    def __init__(self, eng, store: Store):
+        self.e, self.store = eng, store
+        store.nparts = eng.ctx.parts("ssdseg_channel_stats_parts", store.m, store.c)
+        store.stats = eng.ctx.empty((store.nparts, 2, store.c))
+
+    def fwd(self):
+        s = self.store
+        self.e.ctx.call("ssdseg_channel_stats", s.buf, s.ld, s.m, s.c, s.stats)
+
+
+class ApplyOp(Op):
+    """out = view(a) (+ view(b)): Add, materialisation, copies into concat slices"""
+
+    def __init__(self, eng, a: Val, b: Optional[Val], out: Store, name: str):
+        self.e, self.a, self.b, self.out, self.name = eng, a, b, out, name
+
+    def fwd(self):
+        a, b, o = self.a, self.b, self.out
+        self.e.ctx.call("ssdseg_bn_apply", a.view(), a.store.ld, b.view() if b is not None else None, b.store.ld if b is not None else 0,
+                        o.buf, o.ld, o.m, o.c)
+
+    def bwd(self):
+        o = self.out
+        for v in (self.a, self.b):
+            if v is None or not v.store.need_grad:
+                continue
+            # d(out)/d(activated value) = 1 (the activation mask is applied by the producer's BN/ReLU backward)
+            g, acc = v.store.grad_slot()
+            self.e.ctx.call("ssdseg_axpby", o.grad, o.ld, g, v.store.ld, o.m, o.c, 1.0, 1.0 if acc else 0.0)
+
+
+class GapOp(Op):
+    def __init__(self, eng, inp: Val, out: Store, name):
+        self.e, self.inp, self.out, self.name = eng, inp, out, name
+        assert inp.store.ld == inp.store.c
+
+    def fwd(self):
+        s = self.inp.store
+        self.e.ctx.call("ssdseg_gap_fwd", self.inp.view(), self.out.buf, s.n, s.h * s.w, s.c)
+
+    def bwd(self):
+        s = self.inp.store
+        if s.need_grad:
+            dx, acc = s.grad_slot()
+            self.e.ctx.call("ssdseg_gap_bwd", self.out.grad, dx, s.n, s.h * s.w, s.c, acc)
+
+
+class BilinearOp(Op):
+    def __init__(self, eng, inp: Val, out: Store, fy: int, fx: int, name):
+        self.e, self.inp, self.out, self.fy, self.fx, self.name = eng, inp, out, fy, fx, name
+
+    def fwd(self):
+        s = self.inp.store
+        self.e.ctx.call("ssdseg_bilinear_fwd", self.inp.view(), s.ld, self.out.buf, self.out.ld, s.n, s.h, s.w, s.c, self.fy, self.fx)
+
+    def bwd(self):
+        s = self.inp.store
+        if s.need_grad:
+            dx, acc = s.grad_slot()
+            self.e.ctx.call("ssdseg_bilinear_bwd", self.out.grad, self.out.ld, dx, s.ld, s.n, s.h, s.w, s.c, self.fy, self.fx, acc)
+
+
+class MaskHeadOp(Op):
+    """logits --bilinear x(fy,fx)--> softmax (= output-mask) [--> weighted cross-entropy]"""
+
+    def __init__(self, eng, logits: Val, fy, fx, name, prob: Optional[Store]):
+        self.e, self.logits, self.fy, self.fx, self.name, self.prob = eng, logits, fy, fx, name, prob
+        s = logits.store
+        assert logits.scale is None and logits.act == ACT_NONE and s.ld == s.c
+        self.y_true: Optional[H.DeviceBuffer] = None
+        self.class_weights: Optional[H.DeviceBuffer] = None
+        self.loss: Optional[H.DeviceBuffer] = None
+        self.loss_scale = 0.0
+
+    def fwd(self):
+        s = self.logits.store
+        self.e.ctx.call("ssdseg_mask_head_fwd", s.buf, s.n, s.h, s.w, s.c, self.fy, self.fx, self.y_true if self.loss is not None else None,
+                        self.class_weights, self.prob.buf if self.prob is not None else None, self.loss)
+
+    def bwd(self):
+        if self.loss is None:
+            return
+        s = self.logits.store
+        g, acc = s.grad_slot()
+        assert acc == 0
+        self.e.ctx.call("ssdseg_mask_head_bwd", s.buf, s.n, s.h, s.w, s.c, self.fy, self.fx, self.y_true, self.class_weights, self.loss_scale, g)
+
+
+class HeadGatherOp(Op):
+    """act(bn(head)) of one SSD feature map, viewed as (B, H*W*boxes, 4), written at its anchor offset of the
+    (B, anchors, 4) concat (reference blocks.py:155 Reshape + models.py:256/271 Concatenate axis=1)"""
+
+    def __init__(self, eng, inp: Val, out: Store, anchor_offset: int, anchors_total: int, name):
+        self.e, self.inp, self.out, self.off, self.total, self.name = eng, inp, out, anchor_offset, anchors_total, name
+
+    def fwd(self):
+        s = self.inp.store
+        self.e.ctx.call("ssdseg_head_gather", self.inp.view(), self.out.buf, s.n, s.h * s.w * s.c, s.c, self.off * 4, self.total * 4, 0)
+
+    def bwd(self):
+        s = self.inp.store
+        g, acc = s.grad_slot()
+        assert acc == 0
+        self.e.ctx.call("ssdseg_head_gather", H.view(self.out.grad), g, s.n, s.h * s.w * s.c, s.c, self.off * 4, self.total * 4, 1)
+
+
+class SoftmaxRowsOp(Op):
+    def __init__(self, eng, inp: Store, out: Store, name):
+        self.e, self.inp, self.out, self.name = eng, inp, out, name
+
+    def fwd(self):
+        self.e.ctx.call("ssdseg_softmax_rows", H.view(self.inp.buf), self.out.buf, self.inp.m, self.inp.c)
+
+
+class DetLossOp(Op):
+    """confidence + localization losses; the gradients w.r.t. the pre-softmax logits / box offsets are produced in
+    the forward call (fused) and simply stay in the concat stores' gradient buffers."""
+
+    def __init__(self, eng, logits: Store, probs: Store, boxes: Store):
+        self.e, self.logits, self.probs, self.boxes = eng, logits, probs, boxes
+        self.name = "det-loss"
+        b = probs.n
+        self.y_labels = self.y_boxes = None
+        self.conf_loss, self.loc_loss = eng.ctx.empty(b), eng.ctx.empty(b)
+        self.w_conf = self.w_loc = 1.0
+
+    def fwd(self):
+        p = self.probs
+        if not self.e.training:
+            return
+        assert self.w_conf == self.w_loc, "per-output loss weights must match for the fused detection loss"
+        self.e.ctx.call("ssdseg_det_loss", self.y_labels, p.buf, self.y_boxes, self.boxes.buf, p.n, p.h * p.w, p.c, self.w_conf / p.n,
+                        self.conf_loss, self.loc_loss, self.logits.grad, self.boxes.grad, None)
+
+    def bwd(self):
+        self.logits.gwritten = True
+        self.boxes.gwritten = True
+
+
+class DecodeNmsOp(Op):
+    def __init__(self, eng, boxes: Store, probs: Store, decode: L.DecodeBoxesCentroidsOffsets, nms: L.NonMaximumSuppression,
+                 suppress_with: Optional[Store], out: Store):
+        self.e, self.boxes, self.probs, self.nms, self.mask, self.out = eng, boxes, probs, nms, suppress_with, out
+        ctx = eng.ctx
+        a = boxes.h * boxes.w
+        cent = np.stack([decode.center_x_boxes_default, decode.center_y_boxes_default, decode.width_boxes_default,
+                         decode.height_boxes_default], axis=1).astype(np.float32)
+        assert cent.shape == (a, 4)
+        self.centroids = ctx.array(cent)
+        self.stds = (C.c_float * 4)(decode.standard_deviation_center_x_offsets, decode.standard_deviation_center_y_offsets,
+                                    decode.standard_deviation_width_offsets, decode.standard_deviation_height_offsets)
+        self.corners = ctx.empty((boxes.n, a, 4))
+        self.probs_s = ctx.empty((probs.n, a, probs.c)) if suppress_with is not None else None
+        self.valid = ctx.empty(boxes.n, np.int32)
+        self.name = nms.name
+
+    def fwd(self):
+        b, a, c = self.boxes.n, self.boxes.h * self.boxes.w, self.probs.c
+        ctx = self.e.ctx
+        ctx.call("ssdseg_decode_boxes", self.boxes.buf, self.centroids, b, a, self.stds, self.corners)
+        probs = self.probs.buf
+        if self.mask is not None:
+            m = self.mask
+            ctx.call("ssdseg_seg_suppress", m.buf, m.m, m.c, probs, b * a, self.probs_s)
+            probs = self.probs_s
+        n = self.nms
+        ctx.call("ssdseg_combined_nms", self.corners, probs, b, a, c, n.max_number_of_boxes_per_class, n.max_number_of_boxes_per_sample,
+                 float(n.boxes_iou_threshold), float(n.labels_probability_threshold), self.out.buf, self.valid)
+
+
+# ====================================================================================================== engine
+class Engine:
+    """One lowered instance of a model for a fixed batch size and mode."""
+
+    def __init__(self, model: K.Model, batch_size: int, training: bool, ctx: Optional[H.Context] = None, grad_bucket=None):
+        self.model, self.batch, self.training = model, int(batch_size), bool(training)
+        self.ctx = ctx if ctx is not None else default_context()
+        self.ops: List[Op] = []
+        self.vals: Dict[int, Val] = {}          # id(KTensor) -> Val
+        self.stores: List[Store] = []
+        self.output_vals: List[Val] = []
+        self.loss_ops: Dict[str, Op] = {}
+        self._alloc_params(grad_bucket)
+        self._plan_concats()
+        for layer in model.layers:
+            self._lower(layer)
+        self.output_vals = [self.vals[id(t)] for t in model.outputs]
+        self.adam_step_count = 0
+        self._graph_exec = None
+
+    # ------------------------------------------------------------------ parameters
+    def _alloc_params(self, grad_bucket):
+        holder = getattr(self.model, "_trained", None) or self.model   # an inference model shares its trained model's weights
+        owner = getattr(holder, "_engine_params", None)
+        if owner is None:
+            tr, st = [], []
+            for l in self.model.layers:
+                for wname, arr in l.weights.items():
+                    (tr if (wname in l.trainable_names) else st).append((l, wname, arr))
+            n_tr = sum(a.size for _, _, a in tr)
+            n_st = sum(a.size for _, _, a in st)
+            ctx = self.ctx
+            owner = dict(index={}, n_tr=n_tr, n_st=n_st)
+            flat = np.concatenate([a.reshape(-1) for _, _, a in tr]) if tr else np.zeros(0, np.float32)
+            flat_s = np.concatenate([a.reshape(-1) for _, _, a in st]) if st else np.zeros(0, np.float32)
+            owner["params"] = ctx.array(flat.astype(np.float32))
+            owner["state"] = ctx.array(flat_s.astype(np.float32))
+            off = 0
+            for l, wname, arr in tr:
+                owner["index"][(id(l), wname)] = ("params", off, arr.shape)
+                off += arr.size
+            off = 0
+            for l, wname, arr in st:
+                owner["index"][(id(l), wname)] = ("state", off, arr.shape)
+                off += arr.size
+            owner["grads"] = owner["adam_m"] = owner["adam_v"] = None
+            holder._engine_params = owner
+            for l in self.model.layers:
+                if l.weights:
+                    l._engine_sync = (self._pull_layer, self._push_layer)
+        self.P = owner
+        if self.training and owner["grads"] is None:
+            n = owner["n_tr"]
+            owner["grads"] = grad_bucket if grad_bucket is not None else self.ctx.zeros(n)
+            owner["adam_m"], owner["adam_v"] = self.ctx.zeros(n), self.ctx.zeros(n)
+
+    def _view(self, bucket: str, layer, wname) -> H.DeviceBuffer:
+        which, off, shape = self.P["index"][(id(layer), wname)]
+        src = {"params": self.P[which], "grads": self.P["grads"] if which == "params" else None}[bucket]
+        if src is None:
+            return None
+        return src.view(off, shape)
+
+    def param_view(self, layer, wname):
+        which, off, shape = self.P["index"][(id(layer), wname)]
+        return self.P[which].view(off, shape)
+
+    state_view = param_view
+
+    def grad_view(self, layer, wname):
+        if not self.training:
+            return None
+        which, off, shape = self.P["index"][(id(layer), wname)]
+        assert which == "params"
+        return self.P["grads"].view(off, shape)
+
+    def _pull_layer(self, layer):
+        self.ctx.sync()
+        for wname in layer.weights:
+            layer.weights[wname] = self.param_view(layer, wname).download()
+
+    def _push_layer(self, layer):
+        for wname, arr in layer.weights.items():
+            self.param_view(layer, wname).upload(arr)
+
+    # ------------------------------------------------------------------ planning helpers
+    def _consumers(self) -> Dict[int, List[K.Layer]]:
+        cons: Dict[int, List[K.Layer]] = {}
+        for l in self.model.layers:
+            for t in l.inbound:
+                cons.setdefault(id(t), []).append(l)
+        return cons
+
+    def _plan_concats(self):
+        """channel-axis Concatenate: let each input's storage producer write straight into its slice"""
+        self.cons = self._consumers()
+        self.placement: Dict[int, Tuple[K.Concatenate, int]] = {}   # id(producer layer) -> (concat layer, channel offset)
+        self.concat_store: Dict[int, Store] = {}
+        outs = {id(t) for t in self.model.outputs}
+        for l in self.model.layers:
+            if not isinstance(l, K.Concatenate) or l.axis_resolved != 3:
+                continue
+            off = 0
+            for t in l.inbound:
+                c = t.shape[-1]
+                cur, ok = t, True
+                # walk back through lazily-fused per-channel layers to whoever writes memory
+                while isinstance(cur.layer, (K.ReLU, K.BatchNormalization)):
+                    if len(self.cons.get(id(cur), [])) != 1 or id(cur) in outs:
+                        ok = False
+                        break
+                    cur = cur.layer.inbound[0]
+                prod = cur.layer
+                if ok and isinstance(prod, (K.Conv2D, K.SeparableConv2D, K.UpSampling2D)) and len(self.cons.get(id(cur), [])) == 1 \
+                        and id(cur) not in outs and not (isinstance(prod, K.Conv2D) and prod.kernel_size == (3, 3)):
+                    self.placement[id(prod)] = (l, off)
+                off += c
+
+    def _concat_parts(self, concat: K.Concatenate):
+        """(store, wide scale, wide shift) of a channel concat, created on first use"""
+        key = id(concat)
+        if key not in self.concat_store:
+            n, h, w, c = (self.batch,) + tuple(concat.outputs[0].shape[1:])
+            st = Store(self, n, h, w, c, concat.name)
+            st.wide_scale = self.ctx.array(np.ones(c, np.float32))
+            st.wide_shift = self.ctx.array(np.zeros(c, np.float32))
+            self.concat_store[key] = st
+            self.stores.append(st)
+        return self.concat_store[key]
+
+    def _out_store(self, layer, shape, name=None) -> Tuple[Store, Optional[H.DeviceBuffer], Optional[H.DeviceBuffer]]:
+        """fresh dense store for a layer's raw output, or its slice of a concat buffer"""
+        n, h, w, c = (self.batch,) + tuple(shape[1:])
+        if id(layer) in self.placement:
+            concat, off = self.placement[id(layer)]
+            parent = self._concat_parts(concat)
+            st = parent.slice(off, c, name or layer.name)
+            st.slice_scale = parent.wide_scale.view(off, (c,))
+            st.slice_shift = parent.wide_shift.view(off, (c,))
+            return st
+        st = Store(self, n, h, w, c, name or layer.name)
+        self.stores.append(st)
+        return st
+
+    def _emit(self, op: Op):
+        self.ops.append(op)
+        return op
+
+    def _dense(self, v: Val, name: str) -> Val:
+        """a Val over a dense store (materialise sliced / strided inputs for kernels that need ld == c)"""
+        if v.store.ld == v.store.c:
+            return v
+        s = v.store
+        st = Store(self, s.n, s.h, s.w, s.c, name + ":dense")
+        self.stores.append(st)
+        self._emit(ApplyOp(self, v, None, st, name + ":dense"))
+        return Val(st)
+
+    # ------------------------------------------------------------------ lowering
+    def _lower(self, layer: K.Layer):
+        ins = [self.vals[id(t)] for t in layer.inbound]
+        out_t = layer.outputs[0] if layer.outputs else None
+        setv = lambda v: self.vals.__setitem__(id(out_t), v)
+
+        if isinstance(layer, K.InputLayer):
+            n, h, w, c = (self.batch,) + tuple(out_t.shape[1:])
+            st = Store(self, n, h, w, c, layer.name, need_grad=False)
+            self.stores.append(st)
+            self.input_store = st
+            setv(Val(st))
+        elif isinstance(layer, K.Rescaling):
+            setv(Val(ins[0].store, rescale=(layer.scale, layer.offset)))
+        elif isinstance(layer, K.Conv2D):
+            self._lower_conv(layer, ins[0], setv)
+        elif isinstance(layer, K.DepthwiseConv2D):
+            assert layer.strides[0] == layer.strides[1] and layer.dilation_rate[0] == layer.dilation_rate[1]
+            st = self._out_store(layer, out_t.shape)
+            op = self._emit(DwOp(self, layer, "depthwise_kernel", self._dense(ins[0], layer.name), st, layer.strides[0], layer.dilation_rate[0]))
+            op.out_val = Val(st)
+            setv(op.out_val)
+            st.producer = op
+        elif isinstance(layer, K.SeparableConv2D):
+            assert layer.strides[0] == layer.strides[1] and layer.dilation_rate[0] == layer.dilation_rate[1]
+            inp = self._dense(ins[0], layer.name)
+            s = inp.store
+            n, h, w, _ = (self.batch,) + tuple(out_t.shape[1:])
+            mid = Store(self, n, h, w, s.c, layer.name + ":dw")
+            self.stores.append(mid)
+            dw = self._emit(DwOp(self, layer, "depthwise_kernel", inp, mid, layer.strides[0], layer.dilation_rate[0]))
+            mid.stats = None   # no BatchNormalization between the two halves
+            dw.out_val = Val(mid)
+            st = self._out_store(layer, out_t.shape)
+            pw = self._emit(PwOp(self, layer, "pointwise_kernel", dw.out_val, st))
+            pw.out_val = Val(st)
+            st.producer = pw
+            setv(pw.out_val)
+        elif isinstance(layer, K.BatchNormalization):
+            v = ins[0]
+            assert v.scale is None and v.act == ACT_NONE and v.bn is None, f"{layer.name}: BatchNormalization input must be a raw conv output"
+            st = v.store
+            sc = getattr(st, "slice_scale", None)
+            sh = getattr(st, "slice_shift", None)
+            rec = BNRec(self, layer, st.c, sc, sh)
+            if self.training and st.stats is None:
+                self._emit(ChannelStatsOp(self, st))
+            self._emit(BnOp(self, rec, st))
+            nv = Val(st, rec.scale, rec.shift, ACT_NONE, rec)
+            prod = getattr(st, "producer", None)
+            if prod is not None:
+                prod.out_val = nv
+            setv(nv)
+        elif isinstance(layer, K.ReLU):
+            v = ins[0]
+            act = _act_of(layer)
+            assert v.act == ACT_NONE, f"{layer.name}: stacked activations are not used by ssdseglib"
+            if v.bn is not None:
+                assert len(self.cons.get(id(layer.inbound[0]), [])) == 1, f"{layer.name}: BN output feeds both a ReLU and another layer"
+                v.bn.act = act
+            nv = Val(v.store, v.scale, v.shift, act, v.bn)
+            prod = getattr(v.store, "producer", None)
+            if prod is not None and v.bn is not None:
+                prod.out_val = nv
+            setv(nv)
+        elif isinstance(layer, K.Add):
+            st = self._out_store(layer, out_t.shape)
+            self._emit(ApplyOp(self, ins[1], ins[0], st, layer.name))
+            setv(Val(st))
+        elif isinstance(layer, K.Concatenate):
+            self._lower_concat(layer, ins, setv)
+        elif isinstance(layer, K.GlobalAveragePooling2D):
+            st = self._out_store(layer, out_t.shape)
+            self._emit(GapOp(self, self._dense(ins[0], layer.name), st, layer.name))
+            setv(Val(st))
+        elif isinstance(layer, K.UpSampling2D):
+            cons = self.cons.get(id(out_t), [])
+            if len(cons) == 1 and isinstance(cons[0], K.Softmax):
+                setv(Val(ins[0].store, ins[0].scale, ins[0].shift, ins[0].act, ins[0].bn, lazy_up=layer.size, src=ins[0]))
+            else:
+                st = self._out_store(layer, out_t.shape)
+                self._emit(BilinearOp(self, ins[0], st, layer.size[0], layer.size[1], layer.name))
+                # values are already activated; the concat-wide activation is idempotent on them
+                setv(Val(st, materialised_act=ins[0].act))
+        elif isinstance(layer, K.Softmax):
+            self._lower_softmax(layer, ins[0], setv)
+        elif isinstance(layer, K.Reshape):
+            v = ins[0]
+            setv(Val(v.store, v.scale, v.shift, v.act, v.bn, reshaped=tuple(out_t.shape[1:]), **{k: x for k, x in v.meta.items() if k != "reshaped"}))
+        elif isinstance(layer, L.DecodeBoxesCentroidsOffsets):
+            setv(Val(ins[0].store, decode=layer))
+        elif isinstance(layer, L.SegmentationSuppression):
+            setv(Val(ins[1].store, suppress_with=ins[0].store))
+        elif isinstance(layer, L.NonMaximumSuppression):
+            boxes_v, probs_v = ins[0], ins[1]
+            out = Store(self, self.batch, layer.max_number_of_boxes_per_sample, 1, 6, layer.name, need_grad=False)
+            self.stores.append(out)
+            self._emit(DecodeNmsOp(self, boxes_v.store, probs_v.store, boxes_v.meta["decode"], layer, probs_v.meta.get("suppress_with"), out))
+            setv(Val(out, nms=layer))
+        else:
+            self._lower_shufflenet(layer, ins, setv)
+
+    def _lower_conv(self, layer: K.Conv2D, v: Val, setv):
+        out_t = layer.outputs[0]
+        if "rescale" in v.meta:
+            assert layer.kernel_size == (3, 3) and layer.strides == (2, 2), "Rescaling must feed the 3x3 stride-2 stem"
+            st = self._out_store(layer, out_t.shape)
+            op = self._emit(StemOp(self, layer, v.store, v.meta["rescale"], st))
+        elif layer.kernel_size == (1, 1):
+            assert layer.strides == (1, 1) and not layer.use_bias
+            st = self._out_store(layer, out_t.shape)
+            op = self._emit(PwOp(self, layer, "kernel", v, st))
+        elif layer.kernel_size == (3, 3):
+            assert layer.strides == (1, 1) and not layer.use_bias and layer.dilation_rate == (1, 1)
+            st = self._out_store(layer, out_t.shape)
+            op = self._emit(Conv3Op(self, layer, v, st))
+        else:
+            raise NotImplementedError(f"{layer.name}: Conv2D {layer.kernel_size} stride {layer.strides}")
+        op.out_val = Val(st)
+        st.producer = op
+        setv(op.out_val)
+
+    def _lower_concat(self, layer: K.Concatenate, ins: List[Val], setv):
+        out_t = layer.outputs[0]
+        if layer.axis_resolved == 1 and all("reshaped" in v.meta for v in ins):
+            # SSD heads: (B, boxes_i, 4) blocks stacked along the anchor axis
+            total = out_t.shape[1]
+            st = Store(self, self.batch, total, 1, out_t.shape[2], layer.name)
+            self.stores.append(st)
+            off = 0
+            for v in ins:
+                self._emit(HeadGatherOp(self, Val(v.store, v.scale, v.shift, v.act, v.bn), st, off, total, f"{layer.name}:{v.store.name}"))
+                off += v.meta["reshaped"][0]
+            assert off == total
+            setv(Val(st, head_concat=True))
+            return
+        assert layer.axis_resolved == 3, f"{layer.name}: unsupported concat axis"
+        parent = self._concat_parts(layer)
+        acts = set()
+        off = 0
+        for t, v in zip(layer.inbound, ins):
+            c = t.shape[-1]
+            if v.store.parent is parent and v.store.coff == off:
+                acts.add(v.meta.get("materialised_act", v.act))
+            else:
+                # not placed: copy the activated values into the slice (identity affine there)
+                sl = parent.slice(off, c, f"{layer.name}[{off}:{off + c}]")
+                self._emit(ApplyOp(self, v, None, sl, f"{layer.name}:copy{off}"))
+                acts.add(None)
+            off += c
+        real = {a for a in acts if a is not None}
+        if None in acts:
+            # copied slices hold final values: only legal to keep lazy activations if there are none left
+            assert not real or real == {ACT_NONE}, f"{layer.name}: cannot mix copied and lazily-activated inputs"
+            setv(Val(parent))
+        else:
+            assert len(real) == 1, f"{layer.name}: concat inputs carry different activations {real}"
+            setv(Val(parent, parent.wide_scale, parent.wide_shift, real.pop()))
+
+    def _lower_softmax(self, layer: K.Softmax, v: Val, setv):
+        out_t = layer.outputs[0]
+        if "lazy_up" in v.meta:
+            fy, fx = v.meta["lazy_up"]
+            src: Val = v.meta["src"]
+            n, h, w, c = (self.batch,) + tuple(out_t.shape[1:])
+            prob = None
+            if not self.training or self.keep_mask_probabilities:
+                prob = Store(self, n, h, w, c, layer.name, need_grad=False)
+                self.stores.append(prob)
+            op = self._emit(MaskHeadOp(self, src, fy, fx, layer.name, prob))
+            self.loss_ops[layer.name] = op
+            setv(Val(prob if prob is not None else src.store, mask_head=op))
+        elif v.meta.get("head_concat"):
+            s = v.store
+            st = Store(self, s.n, s.h, s.w, s.c, layer.name, need_grad=False)
+            self.stores.append(st)
+            self._emit(SoftmaxRowsOp(self, s, st, layer.name))
+            setv(Val(st, logits=s))
+        else:
+            raise NotImplementedError(f"{layer.name}: Softmax on this tensor kind")
+
+    def _lower_shufflenet(self, layer, ins, setv):
+        raise NotImplementedError(f"layer type {type(layer).__name__} ({layer.name}) is not lowered yet")
+
+    keep_mask_probabilities = False
+
+    # ------------------------------------------------------------------ execution
+    def set_input(self, images):
+        if isinstance(images, H.DeviceBuffer):
+            if images.ptr != self.input_store.buf.ptr:
+                self.input_store.buf.copy_from(images)
+        else:
+            a = np.ascontiguousarray(images, dtype=np.float32)
+            assert a.shape == (self.batch, self.input_store.h, self.input_store.w, self.input_store.c), f"input shape {a.shape}"
+            self.input_store.buf.upload(a)
+
+    def forward(self):
+        for op in self.ops:
+            op.fwd()
+
+    def backward(self):
+        for s in self.stores:
+            s.gwritten = False
+        for op in reversed(self.ops):
+            op.bwd()
+
+    def seed_output_grad(self, index: int, g):
+        """inject dL/d(output[index]) (bench config 2 / tests): output values are the ACTIVATED tensors"""
+        v = self.output_vals[index]
+        buf = v.store.grad
+        if isinstance(g, H.DeviceBuffer):
+            buf.copy_from(g)
+        else:
+            buf.upload(np.ascontiguousarray(g, np.float32))
+
+    def mark_output_grads_written(self):
+        for v in self.output_vals:
+            v.store.gwritten = True
+
+    def backward_from_outputs(self):
+        for s in self.stores:
+            s.gwritten = False
+        self.mark_output_grads_written()
+        for op in reversed(self.ops):
+            op.bwd()
+
+    def output(self, index: int) -> np.ndarray:
+        """activated value of output `index` as a NumPy array (N, H, W, C) -- for tests / predict"""
+        v = self.output_vals[index]
+        s = v.store
+        if v.scale is None and v.act == ACT_NONE and s.ld == s.c:
+            arr = s.buf.download().reshape(s.n, s.h, s.w, s.ld)
+        else:
+            tmp = self.ctx.empty((s.m, s.c))
+            self.ctx.call("ssdseg_bn_apply", v.view(), s.ld, None, 0, tmp, s.c, s.m, s.c)
+            arr = tmp.download().reshape(s.n, s.h, s.w, s.c)
+        shp = self.model.outputs[index].shape
+        return arr.reshape((s.n,) + tuple(shp[1:]))
+
+    def adam_step(self, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
+        self.adam_step_count += 1
+        P = self.P
+        self.ctx.call("ssdseg_adam_step", P["params"], P["grads"], P["adam_m"], P["adam_v"], C.c_size_t(P["n_tr"]), lr, beta1, beta2, eps,
+                      self.adam_step_count, grad_scale)
+
+
+_default_ctx: Optional[H.Context] = None
+
+
+def default_context() -> H.Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = H.Context(0)
+    return _default_ctx
+
+
+def set_default_context(ctx: H.Context):
+    global _default_ctx
+    _default_ctx = ctx
+
+
+def engine_for(model: K.Model, batch_size: int, training: bool) -> Engine:
+    cache = model.__dict__.setdefault("_engines", {})
+    key = (int(batch_size), bool(training))
+    if key not in cache:
+        cache[key] = Engine(model, batch_size, training)
+    return cache[key]

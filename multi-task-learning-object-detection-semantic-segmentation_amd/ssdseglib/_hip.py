@@ -75,7 +75,7 @@ _SIGNATURES = {
     "ssdseg_bn_finalize": [_vp, _vp, _i, _i, _d, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i],
     "ssdseg_channel_stats_parts": [_i, _i, _ip],
     "ssdseg_channel_stats": [_vp, _vp, _i, _i, _i, _vp],
-    "ssdseg_bn_apply": [_vp, _VP, _i, _vp, _i, _vp, _i, _i, _i],
+    "ssdseg_bn_apply": [_vp, _VP, _i, _VP, _i, _vp, _i, _i, _i],
     "ssdseg_bn_bwd_reduce": [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "ssdseg_axpby": [_vp, _vp, _i, _vp, _i, _i, _i, _f, _f],
     "ssdseg_gap_fwd": [_vp, _VP, _vp, _i, _i, _i],

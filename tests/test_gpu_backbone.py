@@ -1,0 +1,100 @@
+"""GPU parity of the lowered MobileNetV2 backbone (stem, depthwise, pointwise, fused BN/ReLU6, residual adds):
+forward activations and every parameter gradient vs the layer-by-layer NumPy oracle on the same weights/inputs."""
+import numpy as np
+import pytest
+
+from oracle import np_ops as O
+from oracle.np_model import NpModel
+
+pytestmark = pytest.mark.gpu
+
+TAPS = ['backbone-block16-project-batchnorm', 'backbone-block3-expand-relu6', 'backbone-block13-expand-relu6']
+
+
+def build_backbone(shape):
+    import ssdseglib
+    from ssdseglib import _graph as K
+    K.set_seed(7)
+    dummy = np.zeros(4, np.float32)
+    b = ssdseglib.models.MobileNetV2SsdSegBuilder(shape, 6, 4, dummy, dummy, dummy, dummy, (0.1, 0.1, 0.2, 0.2))
+    inp = b._mobilenetv2_backbone()
+    return K.Model(inputs=inp, outputs=[b._layers[n] for n in TAPS])
+
+
+def device_relu_masks(eng, model):
+    """derivative masks of every ReLU as the device sees them: z = scale*y + shift from the resident raw tensors"""
+    masks = {}
+    for l in model.layers:
+        if type(l).__name__ != "ReLU":
+            continue
+        v = eng.vals[id(l.outputs[0])]
+        s = v.store
+        y = s.buf.download().reshape(s.m, s.ld)[:, :s.c].astype(np.float64)
+        z = y if v.scale is None else y * v.scale.download().astype(np.float64) + v.shift.download().astype(np.float64)
+        z = z.astype(np.float32).reshape(s.n, s.h, s.w, s.c)
+        masks[l.name] = O.act_mask(z, v.act)
+    return masks
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.mark.parametrize("batch,shape", [(2, (80, 96, 3)), (3, (96, 128, 3))])
+def test_backbone_forward_backward_parity(ctx, rng, batch, shape):
+    from ssdseglib import _engine as E
+    model = build_backbone(shape)
+    # perturb BN affine so gamma/beta gradients and shifts are exercised
+    for l in model.layers:
+        if type(l).__name__ == "BatchNormalization":
+            c = l.weights["gamma"].size
+            l.weights["gamma"] = rng.uniform(0.7, 1.3, c).astype(np.float32)
+            l.weights["beta"] = rng.normal(0, 0.3, c).astype(np.float32)
+    eng = E.Engine(model, batch, training=True, ctx=ctx)
+    x = rng.integers(0, 256, (batch,) + shape).astype(np.float32)
+    ref = NpModel(model, dtype=np.float64)   # fp64 oracle: the deep BN stack amplifies fp32 rounding of EITHER side
+    ref_out = ref.forward(x, training=True)
+
+    eng.set_input(x)
+    eng.forward()
+    for i, name in enumerate(TAPS):
+        got = eng.output(i)
+        assert got.shape == ref_out[i].shape
+        assert rel(got, ref_out[i]) < 1e-3, name
+
+    gouts = [rng.normal(0, 1, o.shape).astype(np.float32).astype(np.float64) for o in ref_out]
+    ref_grads = ref.backward(gouts, relu_masks=device_relu_masks(eng, model))
+    for i, g in enumerate(gouts):
+        eng.seed_output_grad(i, g)
+    eng.backward_from_outputs()
+    ctx.sync()
+    worst = 0.0
+    for l in model.layers:
+        if not l.weights:
+            continue
+        # a beta feeding (1x1 conv -> training BN) has an exactly-zero true gradient: judge every tensor against the
+        # largest gradient magnitude of its layer, not against its own (possibly pure-noise) magnitude
+        scale = max(np.abs(ref_grads[l.name][w]).max() for w in l.trainable_names)
+        for wname in l.trainable_names:
+            got = eng.grad_view(l, wname).download()
+            want = ref_grads[l.name][wname]
+            err = np.abs(got.astype(np.float64) - want).max() / scale
+            worst = max(worst, err)
+            assert err < 2e-3, f"{l.name}/{wname}: rel err {err:.3e}"
+    print("worst parameter-gradient rel err", worst)
+
+    # moving statistics were updated like Keras does
+    bn = model.get_layer('backbone-block1-expand-batchnorm')
+    cache = ref.cache[bn.name]
+    mm, mv = O.bn_moving_update(np.zeros_like(cache["mean"]), np.ones_like(cache["var"]), cache)
+    got_mm, got_mv = bn.get_weights()[2:4]
+    assert rel(got_mm, mm) < 1e-4 and rel(got_mv, mv) < 1e-4
+
+    # second step on the same engine gives the same gradients (fixed-order reductions -> bit-identical)
+    g1 = eng.P["grads"].download()
+    eng.forward()
+    for i, g in enumerate(gouts):
+        eng.seed_output_grad(i, g)
+    eng.backward_from_outputs()
+    assert np.array_equal(g1, eng.P["grads"].download())

@@ -210,7 +210,7 @@ def test_bn_finalize_apply_bwd(ctx, rng, m, c, parts):
     # apply (+ residual)
     res = rng.normal(0, 1, (m, c)).astype(np.float32)
     out = ctx.empty((m, c))
-    ctx.call("ssdseg_bn_apply", H.view(dy_, scale, shift, O.ACT_RELU6), c, ctx.array(res), c, out, c, m, c)
+    ctx.call("ssdseg_bn_apply", H.view(dy_, scale, shift, O.ACT_RELU6), c, H.view(ctx.array(res)), c, out, c, m, c)
     assert np.abs(out.download() - (O.act_fwd(z_ref, O.ACT_RELU6) + res)).max() < 2e-5
 
     # backward: reduce -> coefficients -> dy through the gradient view formula
