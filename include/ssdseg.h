@@ -96,6 +96,12 @@ int ssdseg_event_create(ssdseg_ctx* ctx, void** out_host);
 int ssdseg_event_destroy(ssdseg_ctx* ctx, void* ev);
 int ssdseg_event_record(ssdseg_ctx* ctx, void* ev);
 int ssdseg_event_elapsed_ms(ssdseg_ctx* ctx, void* ev_start, void* ev_stop, float* ms_host);
+/* Per-kernel timing: while enabled, every kernel launch of this library is bracketed by HIP events on the ctx
+ * stream and aggregated per kernel symbol together with the launch's ALGORITHMIC bytes / flops.
+ * report: one "kernel\tcount\ttotal_ms\tbytes\tflops\n" line per kernel into buf_host. */
+int ssdseg_timing_enable(ssdseg_ctx* ctx, int enable);
+int ssdseg_timing_reset(ssdseg_ctx* ctx);
+int ssdseg_timing_report(ssdseg_ctx* ctx, char* buf_host, size_t buf_len);
 /* hipGraph capture of a sequence of launches on the ctx stream (launch-bound inner loops) */
 int ssdseg_graph_begin(ssdseg_ctx* ctx);
 int ssdseg_graph_end(ssdseg_ctx* ctx, void** graph_exec_host);

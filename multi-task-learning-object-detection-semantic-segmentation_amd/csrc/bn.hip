@@ -7,33 +7,48 @@ namespace {
 
 constexpr int MAX_PARTS = 1024;
 
-// ---- [nparts][len] -> [nslots][len], slot s sums rows s*chunk .. (s+1)*chunk-1 (fixed order)
-__global__ void fold_parts_kernel(const float* __restrict__ part, int nparts, int len, int chunk, float* __restrict__ out) {
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= len) return;
-    const int s = blockIdx.y;
-    int p0 = s * chunk, p1 = p0 + chunk;
-    if (p1 > nparts) p1 = nparts;
-    float acc = 0.f;
-    for (int p = p0; p < p1; ++p) acc += part[(long long)p * len + l];
-    out[(long long)s * len + l] = acc;
+constexpr int RC = 32;   // channels per block of the partial-row reductions
+constexpr int RP = 32;   // partial rows summed in parallel per channel
+
+// Sums part[p][v][ch] over p for v < NV: 32 lanes along p per channel, fp64, fixed order (deterministic).
+// Result valid for threadIdx.y == 0.  red: NV * RP * (RC + 1) doubles of LDS.
+template <int NV>
+__device__ __forceinline__ void reduce_parts(const float* __restrict__ part, int nparts, int c, int ch, double (&tot)[NV], double* red) {
+    double acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+    if (ch < c) {
+        for (int p = threadIdx.y; p < nparts; p += RP) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) acc[v] += (double)part[((long long)p * NV + v) * c + ch];
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) red[(v * RP + threadIdx.y) * (RC + 1) + threadIdx.x] = acc[v];
+    __syncthreads();
+    if (threadIdx.y == 0) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            double s = 0.0;
+            for (int y = 0; y < RP; ++y) s += red[(v * RP + y) * (RC + 1) + threadIdx.x];
+            tot[v] = s;
+        }
+    }
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ stats, int nparts, int c, double count, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float eps, float momentum, float* __restrict__ moving_mean,
-                                   float* __restrict__ moving_var, float* __restrict__ mean_out, float* __restrict__ invstd_out,
-                                   float* __restrict__ scale, float* __restrict__ shift, int training) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= c) return;
+__global__ void __launch_bounds__(RC * RP) bn_finalize_kernel(const float* __restrict__ stats, int nparts, int c, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                                   float* __restrict__ moving_mean, float* __restrict__ moving_var, float* __restrict__ mean_out,
+                                   float* __restrict__ invstd_out, float* __restrict__ scale, float* __restrict__ shift, int training) {
+    __shared__ double red[2 * RP * (RC + 1)];
+    const int ch = blockIdx.x * RC + threadIdx.x;
+    double tot[2] = {0.0, 0.0};
+    if (training) reduce_parts<2>(stats, nparts, c, ch, tot, red);
+    if (threadIdx.y != 0 || ch >= c) return;
     double mean, var;
     if (training) {
-        double s = 0.0, q = 0.0;
-        for (int p = 0; p < nparts; ++p) {
-            s += (double)stats[((long long)p * 2 + 0) * c + ch];
-            q += (double)stats[((long long)p * 2 + 1) * c + ch];
-        }
-        mean = s / count;
-        var = q / count - mean * mean;
+        mean = tot[0] / count;
+        var = tot[1] / count - mean * mean;
         if (var < 0.0) var = 0.0;
         if (moving_mean != nullptr) {
             const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
@@ -45,11 +60,9 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, int nparts, 
         var = (double)moving_var[ch];
     }
     const double invstd = 1.0 / sqrt(var + (double)eps);
-    const float sc = (float)((double)gamma[ch] * invstd);
-    const float mf = (float)mean;
-    if (mean_out) mean_out[ch] = mf;
+    if (mean_out) mean_out[ch] = (float)mean;
     if (invstd_out) invstd_out[ch] = (float)invstd;
-    scale[ch] = sc;
+    scale[ch] = (float)((double)gamma[ch] * invstd);
     shift[ch] = (float)((double)beta[ch] - mean * (double)gamma[ch] * invstd);
 }
 
@@ -127,21 +140,29 @@ __global__ void __launch_bounds__(512) bn_bwd_partial_kernel(const float* __rest
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int c, double count, const float* __restrict__ scale,
-                                       const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, float* __restrict__ k1, float* __restrict__ k0) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= c) return;
-    double db = 0.0, dg = 0.0;
-    for (int p = 0; p < nparts; ++p) {
-        db += (double)part[((long long)p * 2 + 0) * c + ch];
-        dg += (double)part[((long long)p * 2 + 1) * c + ch];
-    }
+__global__ void __launch_bounds__(RC * RP) bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int c, double count,
+                                       const float* __restrict__ scale, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ k1, float* __restrict__ k0) {
+    __shared__ double red[2 * RP * (RC + 1)];
+    const int ch = blockIdx.x * RC + threadIdx.x;
+    double tot[2] = {0.0, 0.0};
+    reduce_parts<2>(part, nparts, c, ch, tot, red);
+    if (threadIdx.y != 0 || ch >= c) return;
+    const double db = tot[0], dg = tot[1];
     if (dgamma) dgamma[ch] = (float)dg;
     if (dbeta) dbeta[ch] = (float)db;
     const double s = scale[ch], is = invstd[ch], mu = mean[ch];
     k1[ch] = (float)(-s * dg * is / count);
     k0[ch] = (float)(s * (dg * is * mu - db) / count);
+}
+
+// out[l] = sum_p part[p][l]
+__global__ void __launch_bounds__(RC * RP) colsum_kernel(const float* __restrict__ part, int nparts, int len, float* __restrict__ out) {
+    __shared__ double red[RP * (RC + 1)];
+    const int l = blockIdx.x * RC + threadIdx.x;
+    double tot[1] = {0.0};
+    reduce_parts<1>(part, nparts, len, l, tot, red);
+    if (threadIdx.y == 0 && l < len) out[l] = (float)tot[0];
 }
 
 __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift, int act,
@@ -206,6 +227,13 @@ int ew_blocks(long long total) {
 
 }  // namespace
 
+// shared with other translation units: out[l] = sum over nparts rows of part[p][l]
+int ssdseg_colsum(ssdseg_ctx* ctx, const float* part, int nparts, long long len, float* out) {
+    SSDSEG_LAUNCH(ctx, 4.0 * nparts * len, 0.0, colsum_kernel, dim3(cdiv(len, RC)), dim3(RC, RP), 0, part, nparts, (int)len, out);
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" {
 
 int ssdseg_bn_finalize(ssdseg_ctx* ctx, const float* stats, int nparts, int c, double count, const float* gamma,
@@ -221,23 +249,8 @@ int ssdseg_bn_finalize(ssdseg_ctx* ctx, const float* stats, int nparts, int c, d
     SSDSEG_ARG((moving_mean == nullptr) == (moving_var == nullptr), 11);
     SSDSEG_ARG(scale != nullptr, 14);
     SSDSEG_ARG(shift != nullptr, 15);
-    const float* src = stats;
-    int np = nparts;
-    if (training && nparts > 256) {
-        // fold the partial rows 64-fold first so the per-channel pass stays short
-        const int slots = 64, len = 2 * c;
-        const int chunk = cdiv(nparts, slots);
-        const int used = cdiv(nparts, chunk);
-        void* ws;
-        int rc = ssdseg_workspace(ctx, (size_t)used * len * sizeof(float), &ws);
-        if (rc) return rc;
-        hipLaunchKernelGGL(fold_parts_kernel, dim3(cdiv(len, 128), used), dim3(128), 0, ctx->stream, stats, nparts, len, chunk, (float*)ws);
-        SSDSEG_LAUNCH_CHECK();
-        src = (const float*)ws;
-        np = used;
-    }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(c, 64)), dim3(64), 0, ctx->stream, src, np, c, count, gamma, beta, eps, momentum,
-                       moving_mean, moving_var, mean, invstd, scale, shift, training);
+    SSDSEG_LAUNCH(ctx, 8.0 * nparts * c, 0.0, bn_finalize_kernel, dim3(cdiv(c, RC)), dim3(RC, RP), 0, stats, nparts, c, count, gamma, beta, eps,
+                  momentum, moving_mean, moving_var, mean, invstd, scale, shift, training);
     SSDSEG_LAUNCH_CHECK();
     return 0;
 }
@@ -263,7 +276,7 @@ int ssdseg_channel_stats(ssdseg_ctx* ctx, const float* x, int ld, int m, int c, 
     RowGeom g;
     RowLaunch l;
     row_launch(m, c, &g, &l);
-    hipLaunchKernelGGL(channel_stats_kernel, l.grid, l.block, l.lds, ctx->stream, x, ld, g, stats);
+    SSDSEG_LAUNCH(ctx, 4.0 * m * c, 0.0, channel_stats_kernel, l.grid, l.block, l.lds, x, ld, g, stats);
     SSDSEG_LAUNCH_CHECK();
     return 0;
 }
@@ -280,7 +293,7 @@ int ssdseg_bn_apply(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssdse
     SSDSEG_ARG(m > 0, 8);
     SSDSEG_ARG(c > 0 && c % 4 == 0, 9);
     const long long total = (long long)m * (c / 4);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(total)), dim3(256), 0, ctx->stream, in->x, in->scale, in->shift, in->act, ldx,
+    SSDSEG_LAUNCH(ctx, 4.0 * m * c * (residual ? 3 : 2), 0.0, bn_apply_kernel, dim3(ew_blocks(total)), dim3(256), 0, in->x, in->scale, in->shift, in->act, ldx,
                        residual ? residual->x : nullptr, residual ? residual->scale : nullptr, residual ? residual->shift : nullptr,
                        residual ? residual->act : 0, ldr, out, ldo, (long long)m, c / 4);
     SSDSEG_LAUNCH_CHECK();
@@ -305,10 +318,10 @@ int ssdseg_bn_bwd_reduce(ssdseg_ctx* ctx, const float* g, int ldg, const float* 
     void* ws;
     int rc = ssdseg_workspace(ctx, (size_t)l.grid.x * 2 * c * sizeof(float), &ws);
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, l.grid, l.block, l.lds, ctx->stream, g, ldg, y, ldy, rg, scale, shift, mean, invstd, act,
+    SSDSEG_LAUNCH(ctx, 8.0 * m * c, 0.0, bn_bwd_partial_kernel, l.grid, l.block, l.lds, g, ldg, y, ldy, rg, scale, shift, mean, invstd, act,
                        (float*)ws);
     SSDSEG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(c, 64)), dim3(64), 0, ctx->stream, (const float*)ws, (int)l.grid.x, c, (double)m,
+    SSDSEG_LAUNCH(ctx, 8.0 * l.grid.x * c, 0.0, bn_bwd_finalize_kernel, dim3(cdiv(c, RC)), dim3(RC, RP), 0, (const float*)ws, (int)l.grid.x, c, (double)m,
                        scale, mean, invstd, dgamma, dbeta, k1, k0);
     SSDSEG_LAUNCH_CHECK();
     return 0;
@@ -323,7 +336,7 @@ int ssdseg_axpby(ssdseg_ctx* ctx, const float* src, int lds, float* dst, int ldd
     SSDSEG_ARG(m > 0, 6);
     SSDSEG_ARG(c > 0 && c % 4 == 0, 7);
     const long long total = (long long)m * (c / 4);
-    hipLaunchKernelGGL(axpby_kernel, dim3(ew_blocks(total)), dim3(256), 0, ctx->stream, src, lds, dst, ldd, (long long)m, c / 4, a, b);
+    SSDSEG_LAUNCH(ctx, 4.0 * m * c * (b != 0.f ? 3 : 2), 0.0, axpby_kernel, dim3(ew_blocks(total)), dim3(256), 0, src, lds, dst, ldd, (long long)m, c / 4, a, b);
     SSDSEG_LAUNCH_CHECK();
     return 0;
 }

@@ -7,6 +7,8 @@
 
 #include "ssdseg.h"
 
+struct ssdseg_timing;  // per-kernel HIP-event timing registry (runtime.hip)
+
 struct ssdseg_ctx {
     int device;
     hipStream_t stream;
@@ -15,7 +17,20 @@ struct ssdseg_ctx {
     size_t workspace_bytes;
     int num_cus;
     bool capturing;
+    ssdseg_timing* timing;  // non-null while kernel timing is enabled
 };
+
+// Brackets one kernel launch with HIP events on the ctx stream when timing is enabled (bench.py's roofline leg);
+// `bytes`/`flops` are the ALGORITHMIC traffic / work of this launch (formulas: DESIGN.md "Kernels").
+void ssdseg_timing_begin(ssdseg_ctx* ctx, const char* kernel, double bytes, double flops);
+void ssdseg_timing_end(ssdseg_ctx* ctx);
+
+#define SSDSEG_LAUNCH(ctx, bytes, flops, kernel, grid, block, lds, ...)               \
+    do {                                                                              \
+        if ((ctx)->timing) ssdseg_timing_begin((ctx), #kernel, (bytes), (flops));     \
+        hipLaunchKernelGGL(kernel, grid, block, lds, (ctx)->stream, __VA_ARGS__);     \
+        if ((ctx)->timing) ssdseg_timing_end((ctx));                                  \
+    } while (0)
 
 void ssdseg_set_error(const char* fmt, ...);
 int ssdseg_hip_fail(hipError_t e, const char* what);

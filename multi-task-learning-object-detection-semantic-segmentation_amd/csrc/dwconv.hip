@@ -14,7 +14,7 @@
 namespace {
 
 constexpr int TW = 4;           // outputs per strip
-constexpr int MAX_BLOCKS = 2048;
+constexpr int MAX_BLOCKS = 1024;  // also the number of BN-stat / dW partial rows
 
 struct DwGeom {
     int n, h, w, c, ho, wo, s, d, pt, pl;
@@ -298,15 +298,6 @@ __global__ void __launch_bounds__(512) dw_bwd_kernel(DwGeom gm, ViewDev in, cons
     }
 }
 
-// out[l] = sum_p part[p][l]   (fixed order -> deterministic)
-__global__ void colsum_kernel(const float* __restrict__ part, int nparts, long long len, float* __restrict__ out) {
-    long long l = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= len) return;
-    float acc = 0.f;
-    for (int p = 0; p < nparts; ++p) acc += part[(long long)p * len + l];
-    out[l] = acc;
-}
-
 struct DwLaunch {
     dim3 grid, block;
     size_t lds;
@@ -334,13 +325,7 @@ bool dw_geometry(int n, int h, int w, int c, int stride, int dilation, DwGeom* g
 
 }  // namespace
 
-// shared with other translation units
-int ssdseg_colsum(ssdseg_ctx* ctx, const float* part, int nparts, long long len, float* out) {
-    int threads = 256;
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(len, threads)), dim3(threads), 0, ctx->stream, part, nparts, len, out);
-    SSDSEG_LAUNCH_CHECK();
-    return 0;
-}
+int ssdseg_colsum(ssdseg_ctx* ctx, const float* part, int nparts, long long len, float* out);  // bn.hip
 
 extern "C" {
 
@@ -373,12 +358,15 @@ int ssdseg_dwconv_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, fl
     DwLaunch l;
     dw_geometry(n, h, wdt, c, stride, dilation, &g, &l);
     ViewDev v{in->x, in->scale, in->shift, in->act};
+    // algorithmic traffic: read X, write Y, read W
+    const double cost_bytes = 4.0 * ((double)n * h * wdt * c + (double)n * g.ho * g.wo * c + 9.0 * c);
+    const double cost_flops = 18.0 * n * g.ho * g.wo * c;
     if (dilation == 1 && stride == 1)
-        hipLaunchKernelGGL((dw_fwd_kernel<1, 1>), l.grid, l.block, l.lds, ctx->stream, g, v, w, y, stats);
+        SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_fwd_kernel<1, 1>), l.grid, l.block, l.lds, g, v, w, y, stats);
     else if (dilation == 1)
-        hipLaunchKernelGGL((dw_fwd_kernel<2, 1>), l.grid, l.block, l.lds, ctx->stream, g, v, w, y, stats);
+        SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_fwd_kernel<2, 1>), l.grid, l.block, l.lds, g, v, w, y, stats);
     else
-        hipLaunchKernelGGL((dw_fwd_kernel<1, 0>), l.grid, l.block, l.lds, ctx->stream, g, v, w, y, stats);
+        SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_fwd_kernel<1, 0>), l.grid, l.block, l.lds, g, v, w, y, stats);
     SSDSEG_LAUNCH_CHECK();
     return 0;
 }
@@ -405,8 +393,11 @@ int ssdseg_dwconv_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, co
     float* part = (float*)ws;
     ViewDev v{in->x, in->scale, in->shift, in->act};
     GViewDev gv{dy->g, dy->y, dy->scale, dy->shift, dy->k1, dy->k0, dy->act};
+    // algorithmic traffic: read X, read dY, write dX, read W, write dW
+    const double cost_bytes = 4.0 * (2.0 * n * h * wdt * c + (double)n * g.ho * g.wo * c + 18.0 * c);
+    const double cost_flops = 36.0 * n * g.ho * g.wo * c;
 #define DW_BWD(S_, D_, PT_, PL_) \
-    hipLaunchKernelGGL((dw_bwd_kernel<S_, D_, PT_, PL_>), l.grid, l.block, l.lds, ctx->stream, g, v, w, gv, dx, part, accumulate)
+    SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_bwd_kernel<S_, D_, PT_, PL_>), l.grid, l.block, l.lds, g, v, w, gv, dx, part, accumulate)
     if (dilation != 1) DW_BWD(1, 0, 0, 0);
     else if (stride == 1) DW_BWD(1, 1, 1, 1);
     else if (g.pt == 0 && g.pl == 0) DW_BWD(2, 1, 0, 0);

@@ -57,8 +57,8 @@ __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
 
     const int t = threadIdx.x;
     const int wave = t >> 6, lane = t & 63, li = lane & 31, hh = lane >> 5;
-    const int m0 = blockIdx.y * BM;
     const int j0 = blockIdx.x * BN;
+    const int mtiles = (p.I + BM - 1) / BM;
     const int KT = (p.R + BK - 1) / BK;
     const bool affine = p.cs != nullptr;
 
@@ -67,6 +67,7 @@ __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
     float4 areg[4];
     float4 breg[WN];
 
+    int m0 = 0;
     auto load_tiles = [&](int kt) {
         const int r = kt * BK + a_c4 * 4;
         const bool rin = r < p.R;
@@ -125,6 +126,13 @@ __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
         }
     };
 
+    float ssum[WN], ssq[WN];   // BN statistics of this block's rows, carried across its row tiles
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt) ssum[nt] = ssq[nt] = 0.f;
+
+    // a block walks row tiles blockIdx.y, blockIdx.y + gridDim.y, ... so the number of BN partial rows stays small
+    for (int mt = blockIdx.y; mt < mtiles; mt += gridDim.y) {
+    m0 = mt * BM;
     f32x16 acc[WN];
 #pragma unroll
     for (int nt = 0; nt < WN; ++nt)
@@ -175,13 +183,20 @@ __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
     }
     if (MODE == 0 && p.stats != nullptr) {
         // per-channel (sum, sumsq) of this 128-row tile; padded rows are exactly zero
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { ssum[nt] += acc[nt][e]; ssq[nt] = fmaf(acc[nt][e], acc[nt][e], ssq[nt]); }
+        }
+    }
+    }  // row-tile loop
+
+    if (MODE == 0 && p.stats != nullptr) {
         __syncthreads();
         float* red = smem;  // [4 waves][2][BN]
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt) {
-            float s = 0.f, q = 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { s += acc[nt][e]; q = fmaf(acc[nt][e], acc[nt][e], q); }
+            float s = ssum[nt], q = ssq[nt];
             s += __shfl_xor(s, 32, 64);
             q += __shfl_xor(q, 32, 64);
             if (hh == 0) {
@@ -365,20 +380,32 @@ int pick_wn(int n) {
     return best;
 }
 
+// row-tile slots per column tile: enough blocks to fill the chip (~8 per CU), few enough that the BN partial
+// table stays short
+int rowA_grid_y(int rows, int cols) {
+    const int wn = pick_wn(cols);
+    const int ntiles = cdiv(cols, 32 * wn), mtiles = cdiv(rows, BM);
+    int gy = 2048 / ntiles;
+    if (gy < 1) gy = 1;
+    return mtiles < gy ? mtiles : gy;
+}
+
 template <int MODE>
 int launch_rowA(ssdseg_ctx* ctx, const RowAArgs& a) {
     const int wn = pick_wn(a.J);
-    dim3 grid(cdiv(a.J, 32 * wn), cdiv(a.I, BM), 1);
-    if (grid.y > 65535) { ssdseg_set_error("gemm: too many row tiles (%u)", grid.y); return SSDSEG_EINVAL(0); }
+    dim3 grid(cdiv(a.J, 32 * wn), rowA_grid_y(a.I, a.J), 1);
     size_t lds = (size_t)(BM * AS + BK * (32 * wn + 1)) * sizeof(float);
     size_t red = (size_t)(4 * 2 * 32 * wn) * sizeof(float);
     if (red > lds) lds = red;
+    // algorithmic: read the streamed operand and the weights once, write the output once
+    const double cost_bytes = 4.0 * ((double)a.I * a.R + (double)a.I * a.J + (double)a.R * a.J);
+    const double cost_flops = 2.0 * a.I * a.R * a.J;
     switch (wn) {
-        case 1: hipLaunchKernelGGL((gemm_rowA_kernel<1, MODE>), grid, dim3(256), lds, ctx->stream, a); break;
-        case 2: hipLaunchKernelGGL((gemm_rowA_kernel<2, MODE>), grid, dim3(256), lds, ctx->stream, a); break;
-        case 3: hipLaunchKernelGGL((gemm_rowA_kernel<3, MODE>), grid, dim3(256), lds, ctx->stream, a); break;
-        case 4: hipLaunchKernelGGL((gemm_rowA_kernel<4, MODE>), grid, dim3(256), lds, ctx->stream, a); break;
-        default: hipLaunchKernelGGL((gemm_rowA_kernel<5, MODE>), grid, dim3(256), lds, ctx->stream, a); break;
+        case 1: SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (gemm_rowA_kernel<1, MODE>), grid, dim3(256), lds, a); break;
+        case 2: SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (gemm_rowA_kernel<2, MODE>), grid, dim3(256), lds, a); break;
+        case 3: SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (gemm_rowA_kernel<3, MODE>), grid, dim3(256), lds, a); break;
+        case 4: SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (gemm_rowA_kernel<4, MODE>), grid, dim3(256), lds, a); break;
+        default: SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (gemm_rowA_kernel<5, MODE>), grid, dim3(256), lds, a); break;
     }
     SSDSEG_LAUNCH_CHECK();
     return 0;
@@ -389,12 +416,16 @@ int launch_wgrad_wn(ssdseg_ctx* ctx, const WGradArgs& a, int wn, dim3 grid) {
     size_t lds = (size_t)(RW * WR) * (32 * WI + 32 * wn) * sizeof(float);
     size_t red = (size_t)(WR - 1) * WI * wn * 16 * 64 * sizeof(float);
     if (red > lds) lds = red;
+    const double share = 1.0 / ((double)grid.x * grid.y);   // every (k-tile, n-tile) block column re-reads its operands
+    const double cost_bytes = 4.0 * ((double)a.M * a.K + (double)a.M * a.N + (double)a.K * a.N);
+    const double cost_flops = 2.0 * a.M * a.K * a.N;
+    (void)share;
     switch (wn) {
-        case 1: hipLaunchKernelGGL((gemm_wgrad_kernel<WI, WR, 1>), grid, dim3(256), lds, ctx->stream, a); break;
-        case 2: hipLaunchKernelGGL((gemm_wgrad_kernel<WI, WR, 2>), grid, dim3(256), lds, ctx->stream, a); break;
-        case 3: hipLaunchKernelGGL((gemm_wgrad_kernel<WI, WR, 3>), grid, dim3(256), lds, ctx->stream, a); break;
-        case 4: hipLaunchKernelGGL((gemm_wgrad_kernel<WI, WR, 4>), grid, dim3(256), lds, ctx->stream, a); break;
-        default: hipLaunchKernelGGL((gemm_wgrad_kernel<WI, WR, 5>), grid, dim3(256), lds, ctx->stream, a); break;
+        case 1: SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (gemm_wgrad_kernel<WI, WR, 1>), grid, dim3(256), lds, a); break;
+        case 2: SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (gemm_wgrad_kernel<WI, WR, 2>), grid, dim3(256), lds, a); break;
+        case 3: SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (gemm_wgrad_kernel<WI, WR, 3>), grid, dim3(256), lds, a); break;
+        case 4: SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (gemm_wgrad_kernel<WI, WR, 4>), grid, dim3(256), lds, a); break;
+        default: SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (gemm_wgrad_kernel<WI, WR, 5>), grid, dim3(256), lds, a); break;
     }
     SSDSEG_LAUNCH_CHECK();
     return 0;
@@ -408,7 +439,7 @@ int ssdseg_pwconv_parts(int m, int n, int* nparts_host) {
     SSDSEG_ARG(m > 0, 1);
     SSDSEG_ARG(n > 0, 2);
     SSDSEG_ARG(nparts_host != nullptr, 3);
-    *nparts_host = cdiv(m, BM);
+    *nparts_host = rowA_grid_y(m, n);
     return 0;
 }
 

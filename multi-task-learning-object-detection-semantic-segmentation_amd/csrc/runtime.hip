@@ -37,7 +37,113 @@ int ssdseg_workspace(ssdseg_ctx* ctx, size_t bytes, void** out) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------- kernel timing
+#include <map>
+#include <string>
+#include <vector>
+
+struct ssdseg_timing {
+    struct Pending {
+        const char* kernel;
+        hipEvent_t start, stop;
+        double bytes, flops;
+    };
+    struct Stat {
+        long long count = 0;
+        double ms = 0, bytes = 0, flops = 0;
+    };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+    std::map<std::string, Stat> stats;
+};
+
+static hipEvent_t timing_event(ssdseg_timing* t) {
+    if (!t->pool.empty()) {
+        hipEvent_t e = t->pool.back();
+        t->pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+static void timing_fold(ssdseg_ctx* ctx) {
+    ssdseg_timing* t = ctx->timing;
+    if (!t || t->pending.empty()) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& p : t->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
+            auto& s = t->stats[p.kernel];
+            s.count += 1;
+            s.ms += ms;
+            s.bytes += p.bytes;
+            s.flops += p.flops;
+        }
+        t->pool.push_back(p.start);
+        t->pool.push_back(p.stop);
+    }
+    t->pending.clear();
+}
+
+void ssdseg_timing_begin(ssdseg_ctx* ctx, const char* kernel, double bytes, double flops) {
+    ssdseg_timing* t = ctx->timing;
+    if (!t || ctx->capturing) return;
+    if (t->pending.size() >= 8192) timing_fold(ctx);
+    ssdseg_timing::Pending p{kernel, timing_event(t), timing_event(t), bytes, flops};
+    (void)hipEventRecord(p.start, ctx->stream);
+    t->pending.push_back(p);
+}
+
+void ssdseg_timing_end(ssdseg_ctx* ctx) {
+    ssdseg_timing* t = ctx->timing;
+    if (!t || ctx->capturing || t->pending.empty()) return;
+    (void)hipEventRecord(t->pending.back().stop, ctx->stream);
+}
+
 extern "C" {
+
+int ssdseg_timing_enable(ssdseg_ctx* ctx, int enable) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    if (enable && !ctx->timing) ctx->timing = new ssdseg_timing();
+    if (!enable && ctx->timing) {
+        timing_fold(ctx);
+        for (auto e : ctx->timing->pool) (void)hipEventDestroy(e);
+        delete ctx->timing;
+        ctx->timing = nullptr;
+    }
+    return 0;
+}
+
+int ssdseg_timing_reset(ssdseg_ctx* ctx) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    if (ctx->timing) {
+        timing_fold(ctx);
+        ctx->timing->stats.clear();
+    }
+    return 0;
+}
+
+// Writes "kernel\tcount\ttotal_ms\talgorithmic_bytes\tflops\n" lines; returns SSDSEG_EINVAL(3) if buf is too small.
+int ssdseg_timing_report(ssdseg_ctx* ctx, char* buf_host, size_t buf_len) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(buf_host != nullptr && buf_len > 0, 2);
+    buf_host[0] = 0;
+    if (!ctx->timing) return 0;
+    timing_fold(ctx);
+    size_t used = 0;
+    for (auto& kv : ctx->timing->stats) {
+        int n = snprintf(buf_host + used, buf_len - used, "%s\t%lld\t%.6f\t%.0f\t%.0f\n", kv.first.c_str(), kv.second.count, kv.second.ms,
+                         kv.second.bytes, kv.second.flops);
+        if (n < 0 || (size_t)n >= buf_len - used) {
+            ssdseg_set_error("ssdseg_timing_report: buffer of %zu bytes is too small", buf_len);
+            return SSDSEG_EINVAL(3);
+        }
+        used += (size_t)n;
+    }
+    return 0;
+}
 
 const char* ssdseg_last_error(void) { return g_err; }
 int ssdseg_version(void) { return SSDSEG_VERSION; }
@@ -66,6 +172,7 @@ int ssdseg_ctx_create(int device, void* stream, ssdseg_ctx** out_host) {
     c->workspace_bytes = 0;
     c->num_cus = prop.multiProcessorCount;
     c->capturing = false;
+    c->timing = nullptr;
     if (stream) {
         c->stream = (hipStream_t)stream;
         c->owns_stream = false;
@@ -83,10 +190,11 @@ int ssdseg_ctx_create(int device, void* stream, ssdseg_ctx** out_host) {
 
 int ssdseg_ctx_destroy(ssdseg_ctx* ctx) {
     if (!ctx) return 0;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
-    if (ctx->workspace) hipFree(ctx->workspace);
-    if (ctx->owns_stream) hipStreamDestroy(ctx->stream);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ssdseg_timing_enable(ctx, 0);
+    if (ctx->workspace) (void)hipFree(ctx->workspace);
+    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
 }
@@ -214,7 +322,7 @@ int ssdseg_graph_end(ssdseg_ctx* ctx, void** graph_exec_host) {
     SSDSEG_HIP(hipStreamEndCapture(ctx->stream, &graph));
     hipGraphExec_t exec = nullptr;
     hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    hipGraphDestroy(graph);
+    (void)hipGraphDestroy(graph);
     if (e != hipSuccess) return ssdseg_hip_fail(e, "hipGraphInstantiate");
     *graph_exec_host = (void*)exec;
     return 0;

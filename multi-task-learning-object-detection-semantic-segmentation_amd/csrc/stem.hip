@@ -172,7 +172,7 @@ int ssdseg_stem_conv_fwd(ssdseg_ctx* ctx, const float* x, const float* w, const 
     stem_geometry(n, h, wdt, cout, &g, &grid, &block, &lds);
     g.in_scale = in_scale;
     g.in_offset = in_offset;
-    hipLaunchKernelGGL(stem_fwd_kernel, grid, block, lds, ctx->stream, g, x, w, bias, y, stats);
+    SSDSEG_LAUNCH(ctx, 4.0 * ((double)n * h * wdt * CIN + (double)g.npix * cout + 27.0 * cout), 54.0 * g.npix * cout, stem_fwd_kernel, grid, block, lds, g, x, w, bias, y, stats);
     SSDSEG_LAUNCH_CHECK();
     return 0;
 }
@@ -201,7 +201,7 @@ int ssdseg_stem_conv_bwd_weight(ssdseg_ctx* ctx, const float* x, const ssdseg_gv
     float* part = (float*)ws;
     float* reduced = part + part_floats;
     GCoef gc{dy->g, dy->y, dy->scale, dy->shift, dy->k1, dy->k0, dy->act};
-    hipLaunchKernelGGL(stem_bwd_weight_kernel, grid, block, lds, ctx->stream, g, x, gc, part);
+    SSDSEG_LAUNCH(ctx, 4.0 * ((double)n * h * wdt * CIN + (double)g.npix * cout + 27.0 * cout), 54.0 * g.npix * cout, stem_bwd_weight_kernel, grid, block, lds, g, x, gc, part);
     SSDSEG_LAUNCH_CHECK();
     rc = ssdseg_colsum(ctx, part, (int)grid.x, 28LL * cout, reduced);
     if (rc) return rc;

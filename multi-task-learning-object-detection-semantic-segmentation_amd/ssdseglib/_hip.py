@@ -54,6 +54,9 @@ _SIGNATURES = {
     "ssdseg_event_destroy": [_vp, _vp],
     "ssdseg_event_record": [_vp, _vp],
     "ssdseg_event_elapsed_ms": [_vp, _vp, _vp, C.POINTER(_f)],
+    "ssdseg_timing_enable": [_vp, _i],
+    "ssdseg_timing_reset": [_vp],
+    "ssdseg_timing_report": [_vp, C.c_char_p, _sz],
     "ssdseg_graph_begin": [_vp],
     "ssdseg_graph_end": [_vp, C.POINTER(_vp)],
     "ssdseg_graph_launch": [_vp, _vp],
@@ -230,11 +233,15 @@ class Event:
 
 
 def view(x, scale=None, shift=None, act=ACT_NONE) -> ViewStruct:
-    return ViewStruct(_ptr(x), _ptr(scale), _ptr(shift), int(act), 0)
+    v = ViewStruct(_ptr(x), _ptr(scale), _ptr(shift), int(act), 0)
+    v._keep = (x, scale, shift)      # the struct only holds raw pointers: keep the buffers alive with it
+    return v
 
 
 def gview(g, y=None, scale=None, shift=None, k1=None, k0=None, act=ACT_NONE) -> GViewStruct:
-    return GViewStruct(_ptr(g), _ptr(y), _ptr(scale), _ptr(shift), _ptr(k1), _ptr(k0), int(act), 0)
+    v = GViewStruct(_ptr(g), _ptr(y), _ptr(scale), _ptr(shift), _ptr(k1), _ptr(k0), int(act), 0)
+    v._keep = (g, y, scale, shift, k1, k0)
+    return v
 
 
 class Context:
@@ -285,6 +292,23 @@ class Context:
 
     def event(self) -> Event:
         return Event(self)
+
+    # ---- per-kernel HIP-event timing (bench.py roofline leg)
+    def timing(self, enable: bool):
+        _check(self.lib.ssdseg_timing_enable(self.handle, 1 if enable else 0), "ssdseg_timing_enable")
+
+    def timing_reset(self):
+        _check(self.lib.ssdseg_timing_reset(self.handle), "ssdseg_timing_reset")
+
+    def timing_report(self):
+        """-> {kernel symbol: dict(count, ms, bytes, flops)}"""
+        buf = C.create_string_buffer(1 << 16)
+        _check(self.lib.ssdseg_timing_report(self.handle, buf, len(buf)), "ssdseg_timing_report")
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, count, ms, nbytes, flops = line.split("\t")
+            out[name] = dict(count=int(count), ms=float(ms), bytes=float(nbytes), flops=float(flops))
+        return out
 
     # ---- hipGraph capture
     def graph_begin(self):
