@@ -202,10 +202,16 @@ int ssdseg_bilinear_bwd(ssdseg_ctx* ctx, const float* g, int ldg, float* dx, int
  * optionally fused with the weighted cross-entropy (losses.py:294-303): loss[n] = -sum_c w_c sum_px y*log(clip p).
  * prob may be NULL (training does not need it stored); y_true/loss may be NULL (inference). */
 int ssdseg_mask_head_fwd(ssdseg_ctx* ctx, const float* logits, int n, int h, int wdt, int c, int fy, int fx,
-                         const float* y_true, const float* class_weights, float* prob, float* loss);
+                         const float* y_true, const float* class_weights_host, float* prob, float* loss);
 /* dlogits (low resolution) = upsample^T( softmax'( dL/dp ) ), dL/dp = -loss_scale * w_c * y / p inside the clip */
 int ssdseg_mask_head_bwd(ssdseg_ctx* ctx, const float* logits, int n, int h, int wdt, int c, int fy, int fx,
-                         const float* y_true, const float* class_weights, float loss_scale, float* dlogits);
+                         const float* y_true, const float* class_weights_host, float loss_scale, float* dlogits);
+/* SSD head plumbing: Reshape(-1, 4) + Concatenate(axis=1) (blocks.py:155; models.py:256,271).  Forward: the activated
+ * head tensor of one feature map, in[b][in_img_elems] (channel of element r = r % c), is written to
+ * out[b][out_off_elems + r] of a buffer with out_img_elems floats per image.  reverse != 0 copies the other way
+ * (gradient of the concat back to the head; `in->x` is then the concat-side buffer, `out` the head-side one). */
+int ssdseg_head_gather(ssdseg_ctx* ctx, const ssdseg_view* in, float* out, int b, int in_img_elems, int c,
+                       int out_off_elems, int out_img_elems, int reverse);
 
 /* ---------------------------------------------------------------- K13..K15: detection losses
  * softmax over the class axis of head logits (models.py:259) */
@@ -223,7 +229,7 @@ int ssdseg_det_loss(ssdseg_ctx* ctx, const float* y_labels, const float* p_label
 int ssdseg_topk_mask(ssdseg_ctx* ctx, const float* values, int n, int k, uint8_t* mask);
 /* dice / dice_square (losses.py:175-264), API surface only: loss[n] from y_true, p [n][hw][c] */
 int ssdseg_dice_loss(ssdseg_ctx* ctx, const float* y_true, const float* p, int n, int hw, int c,
-                     const float* class_weights, int squared, float* loss);
+                     const float* class_weights_host, int squared, float* loss);
 
 /* ---------------------------------------------------------------- K16: anchor matching + offset encoding
  * DataEncoderDecoder._encode_ground_truth_labels_boxes (datacoder.py:205-300).
@@ -261,6 +267,8 @@ int ssdseg_maxpool3x3s2_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, const float*
 /* channel shuffle (groups) of a concat of two halves: out[.., j*g + i] = in[.., i*(c/g) + j]  (models.py:497-503) */
 int ssdseg_channel_shuffle(ssdseg_ctx* ctx, const float* in, int ldi, float* out, int ldo, int m, int c, int groups,
                            int inverse);
+/* g *= act'(x) in place: backward of a ReLU that follows an Add (ShuffleNetV2 basic unit, models.py:593-595) */
+int ssdseg_act_bwd(ssdseg_ctx* ctx, float* g, int ldg, const float* x, int ldx, int m, int c, int act);
 
 #ifdef __cplusplus
 }

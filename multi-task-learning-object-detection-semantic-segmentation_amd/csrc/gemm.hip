@@ -41,13 +41,16 @@ struct RowAArgs {
     int accumulate;
     float* stats;
     int I, R, J;
+    // dense 3x3 stride-1 SAME convolution as implicit GEMM (CONV kernels): the reduction axis is (tap, channel) with
+    // convC channels per tap, row m = (n, h, w) reads the streamed operand at (h + sign*(kh-1), w + sign*(kw-1))
+    int convH, convW, convC, convSign;
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-template <int WN, int MODE>
+template <int WN, int MODE, bool CONV>
 __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
     constexpr int BN = 32 * WN;
     constexpr int BS = BN + 1;
@@ -68,21 +71,36 @@ __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
     float4 breg[WN];
 
     int m0 = 0;
+    int rn[4], rh[4], rw[4];   // CONV: (image, row, col) of this thread's 4 staged rows, fixed for a row tile
     auto load_tiles = [&](int kt) {
         const int r = kt * BK + a_c4 * 4;
         const bool rin = r < p.R;
+        int ch = r, dh = 0, dw = 0;   // channel inside the tap, spatial offset of the tap
+        if (CONV) {
+            const int tap = r / p.convC;
+            ch = r - tap * p.convC;
+            const int kh = tap / 3;
+            dh = (kh - 1) * p.convSign;
+            dw = (tap - kh * 3 - 1) * p.convSign;
+        }
         float4 cs = f4(0.f), ct = f4(0.f), ck1 = f4(0.f), ck0 = f4(0.f);
         if (affine && rin) {
-            cs = ld4(p.cs + r);
-            ct = ld4(p.ct + r);
-            if (MODE == 1) { ck1 = ld4(p.ck1 + r); ck0 = ld4(p.ck0 + r); }
+            cs = ld4(p.cs + ch);
+            ct = ld4(p.ct + ch);
+            if (MODE == 1) { ck1 = ld4(p.ck1 + ch); ck0 = ld4(p.ck0 + ch); }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + a_r + 32 * i;
             float4 v = f4(0.f);
-            if (rin && m < p.I) {
-                const long long off = (long long)m * p.lda + r;
+            bool ok = rin && m < p.I;
+            long long off = (long long)m * p.lda + r;
+            if (CONV) {
+                const int sh = rh[i] + dh, sw = rw[i] + dw;
+                ok = ok && sh >= 0 && sh < p.convH && sw >= 0 && sw < p.convW;
+                off = (((long long)rn[i] * p.convH + sh) * p.convW + sw) * p.lda + ch;
+            }
+            if (ok) {
                 if (MODE == 0) {
                     v = view_apply4(ld4(p.a0 + off), cs, ct, affine, p.act);
                 } else {
@@ -103,7 +121,9 @@ __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
             } else {
                 const int jj = idx >> 3, r4 = idx & 7;
                 const int gr = kt * BK + r4 * 4, gj = j0 + jj;
-                if (gr < p.R && gj < p.J) v = ld4(p.b + (long long)gj * p.ldb + gr);
+                // CONV: w[tap][j][c] with r = tap*convC + c  ->  j*convC + r + tap*convC*(J-1)
+                const long long tapoff = CONV ? (long long)(gr / p.convC) * p.convC * (p.J - 1) : 0;
+                if (gr < p.R && gj < p.J) v = ld4(p.b + (long long)gj * p.ldb + gr + tapoff);
             }
             breg[q] = v;
         }
@@ -133,6 +153,17 @@ __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
     // a block walks row tiles blockIdx.y, blockIdx.y + gridDim.y, ... so the number of BN partial rows stays small
     for (int mt = blockIdx.y; mt < mtiles; mt += gridDim.y) {
     m0 = mt * BM;
+    if (CONV) {
+        const int hw = p.convH * p.convW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + a_r + 32 * i;
+            rn[i] = m / hw;
+            const int rem = m - rn[i] * hw;
+            rh[i] = rem / p.convW;
+            rw[i] = rem - rh[i] * p.convW;
+        }
+    }
     f32x16 acc[WN];
 #pragma unroll
     for (int nt = 0; nt < WN; ++nt)
@@ -235,6 +266,8 @@ struct WGradArgs {
     float* part;  // [P][K][N]
     int M, K, N;
     int rows_per_split;
+    // one tap of a dense 3x3 conv: row m = (n, h, w) reads x at (h + dh, w + dw); convH == 0 -> plain GEMM
+    int convH, convW, dh, dw;
 };
 
 constexpr int RW = 16;  // reduction rows per wave per step
@@ -273,10 +306,20 @@ __global__ void __launch_bounds__(256) gemm_wgrad_kernel(WGradArgs p) {
                 const int rr = idx / (BI / 4), c4 = idx % (BI / 4);
                 const long long m = mrow + rr;
                 const int k = i0 + c4 * 4;
-                if (m < mend && k < p.K) {
+                bool ok = m < mend && k < p.K;
+                long long src = m;
+                if (p.convH > 0 && ok) {
+                    const long long hw = (long long)p.convH * p.convW;
+                    const long long img = m / hw;
+                    const int rem = (int)(m - img * hw);
+                    const int hy = rem / p.convW + p.dh, wx = rem % p.convW + p.dw;
+                    ok = hy >= 0 && hy < p.convH && wx >= 0 && wx < p.convW;
+                    src = (img * p.convH + hy) * p.convW + wx;
+                }
+                if (ok) {
                     float4 s = f4(0.f), sh = f4(0.f);
                     if (xaff) { s = ld4(p.xs + k); sh = ld4(p.xt + k); }
-                    v = view_apply4(ld4(p.x + m * p.ldx + k), s, sh, xaff, p.xact);
+                    v = view_apply4(ld4(p.x + src * p.ldx + k), s, sh, xaff, p.xact);
                 }
             }
             xreg[q] = v;
@@ -390,7 +433,7 @@ int rowA_grid_y(int rows, int cols) {
     return mtiles < gy ? mtiles : gy;
 }
 
-template <int MODE>
+template <int MODE, bool CONV>
 int launch_rowA(ssdseg_ctx* ctx, const RowAArgs& a) {
     const int wn = pick_wn(a.J);
     dim3 grid(cdiv(a.J, 32 * wn), rowA_grid_y(a.I, a.J), 1);
@@ -401,11 +444,11 @@ int launch_rowA(ssdseg_ctx* ctx, const RowAArgs& a) {
     const double cost_bytes = 4.0 * ((double)a.I * a.R + (double)a.I * a.J + (double)a.R * a.J);
     const double cost_flops = 2.0 * a.I * a.R * a.J;
     switch (wn) {
-        case 1: SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (gemm_rowA_kernel<1, MODE>), grid, dim3(256), lds, a); break;
-        case 2: SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (gemm_rowA_kernel<2, MODE>), grid, dim3(256), lds, a); break;
-        case 3: SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (gemm_rowA_kernel<3, MODE>), grid, dim3(256), lds, a); break;
-        case 4: SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (gemm_rowA_kernel<4, MODE>), grid, dim3(256), lds, a); break;
-        default: SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (gemm_rowA_kernel<5, MODE>), grid, dim3(256), lds, a); break;
+        case 1: SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (gemm_rowA_kernel<1, MODE, CONV>), grid, dim3(256), lds, a); break;
+        case 2: SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (gemm_rowA_kernel<2, MODE, CONV>), grid, dim3(256), lds, a); break;
+        case 3: SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (gemm_rowA_kernel<3, MODE, CONV>), grid, dim3(256), lds, a); break;
+        case 4: SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (gemm_rowA_kernel<4, MODE, CONV>), grid, dim3(256), lds, a); break;
+        default: SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (gemm_rowA_kernel<5, MODE, CONV>), grid, dim3(256), lds, a); break;
     }
     SSDSEG_LAUNCH_CHECK();
     return 0;
@@ -430,6 +473,41 @@ int launch_wgrad_wn(ssdseg_ctx* ctx, const WGradArgs& a, int wn, dim3 grid) {
     SSDSEG_LAUNCH_CHECK();
     return 0;
 }
+
+// picks the tile shape / split count for dw[k][n] = sum_m x[m][k]*dy[m][n], launches, reduces the split partials
+int wgrad_run(ssdseg_ctx* ctx, WGradArgs a, float* dw) {
+    const int m = a.M, k = a.K, n = a.N;
+    const int wn = pick_wn(n);
+    const int wi = k <= 32 ? 1 : (k <= 64 ? 2 : 4);
+    const int wr = 4 / wi;
+    const int brt = RW * wr;
+    const int itiles = cdiv(k, 32 * wi), jtiles = cdiv(n, 32 * wn);
+    long long steps = ((long long)m + brt - 1) / brt;
+    long long want = (4LL * ctx->num_cus + (long long)itiles * jtiles - 1) / ((long long)itiles * jtiles);
+    long long max_splits = (steps + 3) / 4;  // at least 4 steps per block
+    long long splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
+    if (splits > 65535) splits = 65535;
+    long long steps_per_split = (steps + splits - 1) / splits;
+    splits = (steps + steps_per_split - 1) / steps_per_split;
+    a.rows_per_split = (int)(steps_per_split * brt);
+    float* part = dw;
+    if (splits > 1) {
+        void* ws;
+        int rc = ssdseg_workspace(ctx, (size_t)splits * k * n * sizeof(float), &ws);
+        if (rc) return rc;
+        part = (float*)ws;
+    }
+    a.part = part;
+    dim3 grid(jtiles, itiles, (unsigned)splits);
+    int rc;
+    if (wi == 1) rc = launch_wgrad_wn<1, 4>(ctx, a, wn, grid);
+    else if (wi == 2) rc = launch_wgrad_wn<2, 2>(ctx, a, wn, grid);
+    else rc = launch_wgrad_wn<4, 1>(ctx, a, wn, grid);
+    if (rc) return rc;
+    if (splits > 1) return ssdseg_colsum(ctx, part, (int)splits, (long long)k * n, dw);
+    return 0;
+}
+
 
 }  // namespace
 
@@ -460,7 +538,7 @@ int ssdseg_pwconv_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const flo
     a.out = y; a.ldo = ldy;
     a.stats = stats;
     a.I = m; a.R = k; a.J = n;
-    return launch_rowA<0>(ctx, a);
+    return launch_rowA<0, false>(ctx, a);
 }
 
 int ssdseg_pwconv_bwd_data(ssdseg_ctx* ctx, const ssdseg_gview* dy, int ldy, const float* w, float* dx, int ldx, int m,
@@ -483,7 +561,7 @@ int ssdseg_pwconv_bwd_data(ssdseg_ctx* ctx, const ssdseg_gview* dy, int ldy, con
     a.out = dx; a.ldo = ldx;
     a.residual = residual; a.ldr = ldr; a.accumulate = accumulate;
     a.I = m; a.R = n; a.J = k;
-    return launch_rowA<1>(ctx, a);
+    return launch_rowA<1, false>(ctx, a);
 }
 
 int ssdseg_pwconv_bwd_weight(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssdseg_gview* dy, int ldy, float* dw,
@@ -498,39 +576,86 @@ int ssdseg_pwconv_bwd_weight(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, co
     SSDSEG_ARG(m > 0, 7);
     SSDSEG_ARG(k > 0 && k % 4 == 0, 8);
     SSDSEG_ARG(n > 0 && n % 4 == 0, 9);
-    const int wn = pick_wn(n);
-    const int wi = k <= 32 ? 1 : (k <= 64 ? 2 : 4);
-    const int wr = 4 / wi;
-    const int brt = RW * wr;
-    const int itiles = cdiv(k, 32 * wi), jtiles = cdiv(n, 32 * wn);
-    long long steps = ((long long)m + brt - 1) / brt;
-    long long want = (4LL * ctx->num_cus + (long long)itiles * jtiles - 1) / ((long long)itiles * jtiles);
-    long long max_splits = (steps + 3) / 4;  // at least 4 steps per block
-    long long splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
-    if (splits > 65535) splits = 65535;
-    long long steps_per_split = (steps + splits - 1) / splits;
-    splits = (steps + steps_per_split - 1) / steps_per_split;
     WGradArgs a{};
     a.x = in->x; a.xs = in->scale; a.xt = in->shift; a.xact = in->act; a.ldx = ldx;
     a.g = dy->g; a.y = dy->y; a.gs = dy->scale; a.gt = dy->shift; a.gk1 = dy->k1; a.gk0 = dy->k0; a.gact = dy->act;
     a.ldy = ldy;
     a.M = m; a.K = k; a.N = n;
-    a.rows_per_split = (int)(steps_per_split * brt);
-    float* part = dw;
-    if (splits > 1) {
-        void* ws;
-        int rc = ssdseg_workspace(ctx, (size_t)splits * k * n * sizeof(float), &ws);
+    return wgrad_run(ctx, a, dw);
+}
+
+// ------------------------------------------------------------------------------------------------ dense 3x3 (K6)
+int ssdseg_conv3x3_parts(int n, int h, int w, int cout, int* nparts_host) {
+    SSDSEG_ARG(n > 0 && h > 0 && w > 0, 1);
+    SSDSEG_ARG(cout > 0 && cout % 4 == 0, 4);
+    SSDSEG_ARG(nparts_host != nullptr, 5);
+    *nparts_host = rowA_grid_y(n * h * w, cout);
+    return 0;
+}
+
+int ssdseg_conv3x3_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const float* w, float* y, int n, int h, int wdt, int cin,
+                       int cout, float* stats) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(in != nullptr && in->x != nullptr && ((in->scale == nullptr) == (in->shift == nullptr)), 2);
+    SSDSEG_ARG(ldx >= cin && ldx % 4 == 0, 3);
+    SSDSEG_ARG(w != nullptr, 4);
+    SSDSEG_ARG(y != nullptr, 5);
+    SSDSEG_ARG(n > 0 && h > 0 && wdt > 0, 6);
+    SSDSEG_ARG(cin > 0 && cin % 4 == 0, 9);
+    SSDSEG_ARG(cout > 0 && cout % 4 == 0, 10);
+    RowAArgs a{};
+    a.a0 = in->x; a.cs = in->scale; a.ct = in->shift; a.act = in->act; a.lda = ldx;
+    a.b = w; a.ldb = cout;
+    a.out = y; a.ldo = cout;
+    a.stats = stats;
+    a.I = n * h * wdt; a.R = 9 * cin; a.J = cout;
+    a.convH = h; a.convW = wdt; a.convC = cin; a.convSign = 1;
+    return launch_rowA<0, true>(ctx, a);
+}
+
+int ssdseg_conv3x3_bwd_data(ssdseg_ctx* ctx, const ssdseg_gview* dy, const float* w, float* dx, int ldx, int n, int h, int wdt,
+                            int cin, int cout, int accumulate) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(dy != nullptr && dy->g != nullptr, 2);
+    SSDSEG_ARG(dy->scale == nullptr || (dy->y && dy->shift && dy->k1 && dy->k0), 2);
+    SSDSEG_ARG(w != nullptr, 3);
+    SSDSEG_ARG(dx != nullptr, 4);
+    SSDSEG_ARG(ldx >= cin, 5);
+    SSDSEG_ARG(n > 0 && h > 0 && wdt > 0, 6);
+    SSDSEG_ARG(cin > 0 && cin % 4 == 0, 9);
+    SSDSEG_ARG(cout > 0 && cout % 4 == 0, 10);
+    RowAArgs a{};
+    a.a0 = dy->g; a.a1 = dy->y; a.cs = dy->scale; a.ct = dy->shift; a.ck1 = dy->k1; a.ck0 = dy->k0; a.act = dy->act;
+    a.lda = cout;
+    a.b = w; a.ldb = cout;
+    a.out = dx; a.ldo = ldx;
+    a.accumulate = accumulate;
+    a.I = n * h * wdt; a.R = 9 * cout; a.J = cin;
+    a.convH = h; a.convW = wdt; a.convC = cout; a.convSign = -1;   // dx(h,w) gathers dy(h-(kh-1), w-(kw-1))
+    return launch_rowA<1, true>(ctx, a);
+}
+
+int ssdseg_conv3x3_bwd_weight(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssdseg_gview* dy, float* dw, int n, int h,
+                              int wdt, int cin, int cout) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(in != nullptr && in->x != nullptr && ((in->scale == nullptr) == (in->shift == nullptr)), 2);
+    SSDSEG_ARG(ldx >= cin && ldx % 4 == 0, 3);
+    SSDSEG_ARG(dy != nullptr && dy->g != nullptr, 4);
+    SSDSEG_ARG(dy->scale == nullptr || (dy->y && dy->shift && dy->k1 && dy->k0), 4);
+    SSDSEG_ARG(dw != nullptr, 5);
+    SSDSEG_ARG(n > 0 && h > 0 && wdt > 0, 6);
+    SSDSEG_ARG(cin > 0 && cin % 4 == 0, 9);
+    SSDSEG_ARG(cout > 0 && cout % 4 == 0, 10);
+    for (int tap = 0; tap < 9; ++tap) {
+        WGradArgs a{};
+        a.x = in->x; a.xs = in->scale; a.xt = in->shift; a.xact = in->act; a.ldx = ldx;
+        a.g = dy->g; a.y = dy->y; a.gs = dy->scale; a.gt = dy->shift; a.gk1 = dy->k1; a.gk0 = dy->k0; a.gact = dy->act;
+        a.ldy = cout;
+        a.M = n * h * wdt; a.K = cin; a.N = cout;
+        a.convH = h; a.convW = wdt; a.dh = tap / 3 - 1; a.dw = tap % 3 - 1;
+        int rc = wgrad_run(ctx, a, dw + (size_t)tap * cin * cout);
         if (rc) return rc;
-        part = (float*)ws;
     }
-    a.part = part;
-    dim3 grid(jtiles, itiles, (unsigned)splits);
-    int rc;
-    if (wi == 1) rc = launch_wgrad_wn<1, 4>(ctx, a, wn, grid);
-    else if (wi == 2) rc = launch_wgrad_wn<2, 2>(ctx, a, wn, grid);
-    else rc = launch_wgrad_wn<4, 1>(ctx, a, wn, grid);
-    if (rc) return rc;
-    if (splits > 1) return ssdseg_colsum(ctx, part, (int)splits, (long long)k * n, dw);
     return 0;
 }
 

@@ -1,0 +1,427 @@
+// Pooling / resize / head-tail kernels of the DeepLabV3+ and SSDLite heads (all HBM-bound elementwise or gather
+// kernels, float4 over the channel axis, NHWC):
+//   GlobalAveragePooling2D keepdims                (reference blocks.py:57)
+//   UpSampling2D(bilinear), half-pixel centres     (reference blocks.py:61,104,129; semantics SURVEY.md App. B.5)
+//   mask head tail: x4 bilinear -> Softmax -> weighted cross-entropy, fused (blocks.py:128-130 + losses.py:294-303)
+//   SSD head gather: Reshape(-1,4) + Concatenate(axis=1) (blocks.py:155, models.py:256,271) and Softmax (models.py:259)
+#include "common.h"
+
+int ssdseg_colsum(ssdseg_ctx* ctx, const float* part, int nparts, long long len, float* out);
+
+namespace {
+
+__device__ __forceinline__ void add4(float4& a, float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+__device__ __forceinline__ void axpy4(float4& a, float s, float4 b) {
+    a.x = fmaf(s, b.x, a.x); a.y = fmaf(s, b.y, a.y); a.z = fmaf(s, b.z, a.z); a.w = fmaf(s, b.w, a.w);
+}
+
+int ew_blocks(long long total, int threads = 256) {
+    long long b = (total + threads - 1) / threads;
+    return (int)(b < 8192 ? (b < 1 ? 1 : b) : 8192);
+}
+
+// ------------------------------------------------------------------------------------------------ GAP
+// one block per (image, 64-channel-vector group); threads (cv, y) walk the pixels, fixed-order reduction over y
+__global__ void __launch_bounds__(512) gap_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                      int act, float* __restrict__ out, int hw, int c) {
+    extern __shared__ float4 red[];
+    const int cv = c / 4;
+    const int cvi = blockIdx.y * blockDim.x + threadIdx.x;
+    const int n = blockIdx.x;
+    float4 acc = f4(0.f);
+    const bool aff = scale != nullptr;
+    if (cvi < cv) {
+        float4 s = f4(0.f), t = f4(0.f);
+        if (aff) { s = ld4(scale + cvi * 4); t = ld4(shift + cvi * 4); }
+        for (int p = threadIdx.y; p < hw; p += blockDim.y) add4(acc, view_apply4(ld4(x + ((long long)n * hw + p) * c + cvi * 4), s, t, aff, act));
+    }
+    red[threadIdx.y * blockDim.x + threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.y == 0 && cvi < cv) {
+        float4 r = f4(0.f);
+        for (int y = 0; y < (int)blockDim.y; ++y) add4(r, red[y * blockDim.x + threadIdx.x]);
+        const float inv = 1.f / (float)hw;
+        st4(out + (long long)n * c + cvi * 4, make_float4(r.x * inv, r.y * inv, r.z * inv, r.w * inv));
+    }
+}
+
+__global__ void gap_bwd_kernel(const float* __restrict__ g, float* __restrict__ dx, int n, int hw, int cv, int accumulate) {
+    const long long total = (long long)n * hw * cv;
+    const float inv = 1.f / (float)hw;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % cv);
+        const long long img = i / ((long long)hw * cv);
+        float4 v = ld4(g + (img * cv + c4) * 4);
+        v = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+        if (accumulate) add4(v, ld4(dx + i * 4));
+        st4(dx + i * 4, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ bilinear
+// tf.image.resize(bilinear, half_pixel_centers=True): src = (dst + 0.5) * (in/out) - 0.5, clamped to [0, in-1]
+struct Lerp {
+    int i0, i1;
+    float f;
+};
+__device__ __forceinline__ Lerp lerp_of(int dst, int in_size, float inv_factor) {
+    float src = ((float)dst + 0.5f) * inv_factor - 0.5f;
+    src = fminf(fmaxf(src, 0.f), (float)(in_size - 1));
+    Lerp l;
+    l.i0 = (int)floorf(src);
+    l.i1 = l.i0 + 1 < in_size ? l.i0 + 1 : in_size - 1;
+    l.f = src - (float)l.i0;
+    return l;
+}
+// weight with which input index `i` contributes to output index `dst`
+__device__ __forceinline__ float lerp_weight(int dst, int i, int in_size, float inv_factor) {
+    const Lerp l = lerp_of(dst, in_size, inv_factor);
+    return (l.i0 == i ? 1.f - l.f : 0.f) + (l.i1 == i ? l.f : 0.f);
+}
+
+__global__ void bilinear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                    int ldx, float* __restrict__ out, int ldo, int n, int h, int w, int cv, int fy, int fx) {
+    const int ho = h * fy, wo = w * fx;
+    const long long total = (long long)n * ho * wo * cv;
+    const bool aff = scale != nullptr;
+    const float ify = 1.f / (float)fy, ifx = 1.f / (float)fx;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cv) * 4;
+        long long r = i / cv;
+        const int ox = (int)(r % wo); r /= wo;
+        const int oy = (int)(r % ho);
+        const long long img = r / ho;
+        const Lerp ly = lerp_of(oy, h, ify), lx = lerp_of(ox, w, ifx);
+        float4 s = f4(0.f), t = f4(0.f);
+        if (aff) { s = ld4(scale + c0); t = ld4(shift + c0); }
+        const float* base = x + img * h * w * ldx + c0;
+        const float4 v00 = view_apply4(ld4(base + ((long long)ly.i0 * w + lx.i0) * ldx), s, t, aff, act);
+        const float4 v01 = view_apply4(ld4(base + ((long long)ly.i0 * w + lx.i1) * ldx), s, t, aff, act);
+        const float4 v10 = view_apply4(ld4(base + ((long long)ly.i1 * w + lx.i0) * ldx), s, t, aff, act);
+        const float4 v11 = view_apply4(ld4(base + ((long long)ly.i1 * w + lx.i1) * ldx), s, t, aff, act);
+        float4 top, bot, o;
+        top.x = v00.x + (v01.x - v00.x) * lx.f; top.y = v00.y + (v01.y - v00.y) * lx.f; top.z = v00.z + (v01.z - v00.z) * lx.f; top.w = v00.w + (v01.w - v00.w) * lx.f;
+        bot.x = v10.x + (v11.x - v10.x) * lx.f; bot.y = v10.y + (v11.y - v10.y) * lx.f; bot.z = v10.z + (v11.z - v10.z) * lx.f; bot.w = v10.w + (v11.w - v10.w) * lx.f;
+        o.x = top.x + (bot.x - top.x) * ly.f; o.y = top.y + (bot.y - top.y) * ly.f; o.z = top.z + (bot.z - top.z) * ly.f; o.w = top.w + (bot.w - top.w) * ly.f;
+        st4(out + ((img * ho + oy) * wo + ox) * ldo + c0, o);
+    }
+}
+
+// gather form of the transposed resize: each input pixel sums the outputs that referenced it (deterministic)
+__global__ void bilinear_bwd_kernel(const float* __restrict__ g, int ldg, float* __restrict__ dx, int ldx, int n, int h, int w, int cv,
+                                    int fy, int fx, int accumulate) {
+    const int ho = h * fy, wo = w * fx;
+    const long long total = (long long)n * h * w * cv;
+    const float ify = 1.f / (float)fy, ifx = 1.f / (float)fx;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cv) * 4;
+        long long r = i / cv;
+        const int ix = (int)(r % w); r /= w;
+        const int iy = (int)(r % h);
+        const long long img = r / h;
+        // outputs whose source coordinate lies in (iy-1, iy+1): oy in ((iy-0.5)*fy - 0.5, (iy+1.5)*fy - 0.5)
+        int oy0 = (iy == 0) ? 0 : (iy * fy - fy / 2 - fy), oy1 = (iy == h - 1) ? ho - 1 : (iy * fy + fy + fy / 2 + 1);
+        int ox0 = (ix == 0) ? 0 : (ix * fx - fx / 2 - fx), ox1 = (ix == w - 1) ? wo - 1 : (ix * fx + fx + fx / 2 + 1);
+        oy0 = oy0 < 0 ? 0 : oy0; ox0 = ox0 < 0 ? 0 : ox0;
+        oy1 = oy1 > ho - 1 ? ho - 1 : oy1; ox1 = ox1 > wo - 1 ? wo - 1 : ox1;
+        float4 acc = f4(0.f);
+        for (int oy = oy0; oy <= oy1; ++oy) {
+            const float wy = lerp_weight(oy, iy, h, ify);
+            if (wy == 0.f) continue;
+            for (int ox = ox0; ox <= ox1; ++ox) {
+                const float wx = lerp_weight(ox, ix, w, ifx);
+                if (wx == 0.f) continue;
+                axpy4(acc, wy * wx, ld4(g + ((img * ho + oy) * wo + ox) * ldg + c0));
+            }
+        }
+        float* p = dx + ((img * h + iy) * w + ix) * ldx + c0;
+        if (accumulate) add4(acc, ld4(p));
+        st4(p, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ mask head (4 classes)
+constexpr float KEPS = 1e-7f;  // tf.keras.backend.epsilon()
+
+__device__ __forceinline__ float4 softmax4(float4 z) {
+    const float m = fmaxf(fmaxf(z.x, z.y), fmaxf(z.z, z.w));
+    float4 e = make_float4(expf(z.x - m), expf(z.y - m), expf(z.z - m), expf(z.w - m));
+    const float inv = 1.f / (e.x + e.y + e.z + e.w);
+    return make_float4(e.x * inv, e.y * inv, e.z * inv, e.w * inv);
+}
+__device__ __forceinline__ float4 up_logits(const float* __restrict__ logits, long long img, int h, int w, int oy, int ox, float ify, float ifx) {
+    const Lerp ly = lerp_of(oy, h, ify), lx = lerp_of(ox, w, ifx);
+    const float* base = logits + img * h * w * 4;
+    const float4 v00 = ld4(base + ((long long)ly.i0 * w + lx.i0) * 4), v01 = ld4(base + ((long long)ly.i0 * w + lx.i1) * 4);
+    const float4 v10 = ld4(base + ((long long)ly.i1 * w + lx.i0) * 4), v11 = ld4(base + ((long long)ly.i1 * w + lx.i1) * 4);
+    float4 top, bot, o;
+    top.x = v00.x + (v01.x - v00.x) * lx.f; top.y = v00.y + (v01.y - v00.y) * lx.f; top.z = v00.z + (v01.z - v00.z) * lx.f; top.w = v00.w + (v01.w - v00.w) * lx.f;
+    bot.x = v10.x + (v11.x - v10.x) * lx.f; bot.y = v10.y + (v11.y - v10.y) * lx.f; bot.z = v10.z + (v11.z - v10.z) * lx.f; bot.w = v10.w + (v11.w - v10.w) * lx.f;
+    o.x = top.x + (bot.x - top.x) * ly.f; o.y = top.y + (bot.y - top.y) * ly.f; o.z = top.z + (bot.z - top.z) * ly.f; o.w = top.w + (bot.w - top.w) * ly.f;
+    return o;
+}
+__device__ __forceinline__ float clip_log(float p) { return logf(fminf(fmaxf(p, KEPS), 1.f - KEPS)); }
+__device__ __forceinline__ float inside(float p) { return (p >= KEPS && p <= 1.f - KEPS) ? 1.f : 0.f; }
+
+// grid (blocks_per_image, n); partial[n][blocks_per_image] per-image loss partials
+__global__ void __launch_bounds__(256) mask_head_fwd_kernel(const float* __restrict__ logits, int h, int w, int fy, int fx,
+                                                            const float* __restrict__ y_true, float4 cw, float* __restrict__ prob,
+                                                            float* __restrict__ partial) {
+    __shared__ float red[256];
+    const int ho = h * fy, wo = w * fx;
+    const long long npix = (long long)ho * wo;
+    const long long img = blockIdx.y;
+    const float ify = 1.f / (float)fy, ifx = 1.f / (float)fx;
+    float loss = 0.f;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long long)gridDim.x * blockDim.x) {
+        const int ox = (int)(p % wo), oy = (int)(p / wo);
+        const float4 pr = softmax4(up_logits(logits, img, h, w, oy, ox, ify, ifx));
+        const long long off = (img * npix + p) * 4;
+        if (prob) st4(prob + off, pr);
+        if (y_true) {
+            const float4 y = ld4(y_true + off);
+            loss -= cw.x * y.x * clip_log(pr.x) + cw.y * y.y * clip_log(pr.y) + cw.z * y.z * clip_log(pr.z) + cw.w * y.w * clip_log(pr.w);
+        }
+    }
+    if (partial) {
+        red[threadIdx.x] = loss;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) partial[img * gridDim.x + blockIdx.x] = red[0];
+    }
+}
+
+__global__ void mask_loss_final_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ loss, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)partial[(long long)i * nblk + b];
+    loss[i] = (float)s;
+}
+
+// dlogits(low res) = sum over the full-res pixels that interpolate from it of weight * dz, dz = softmax'(dL/dp)
+__global__ void __launch_bounds__(256) mask_head_bwd_kernel(const float* __restrict__ logits, int n, int h, int w, int fy, int fx,
+                                                            const float* __restrict__ y_true, float4 cw, float loss_scale,
+                                                            float* __restrict__ dlogits) {
+    const int ho = h * fy, wo = w * fx;
+    const long long total = (long long)n * h * w;
+    const float ify = 1.f / (float)fy, ifx = 1.f / (float)fx;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ix = (int)(i % w);
+        const int iy = (int)((i / w) % h);
+        const long long img = i / ((long long)w * h);
+        int oy0 = (iy == 0) ? 0 : (iy * fy - fy / 2 - fy), oy1 = (iy == h - 1) ? ho - 1 : (iy * fy + fy + fy / 2 + 1);
+        int ox0 = (ix == 0) ? 0 : (ix * fx - fx / 2 - fx), ox1 = (ix == w - 1) ? wo - 1 : (ix * fx + fx + fx / 2 + 1);
+        oy0 = oy0 < 0 ? 0 : oy0; ox0 = ox0 < 0 ? 0 : ox0;
+        oy1 = oy1 > ho - 1 ? ho - 1 : oy1; ox1 = ox1 > wo - 1 ? wo - 1 : ox1;
+        float4 acc = f4(0.f);
+        for (int oy = oy0; oy <= oy1; ++oy) {
+            const float wy = lerp_weight(oy, iy, h, ify);
+            if (wy == 0.f) continue;
+            for (int ox = ox0; ox <= ox1; ++ox) {
+                const float wx = lerp_weight(ox, ix, w, ifx);
+                if (wx == 0.f) continue;
+                const float4 pr = softmax4(up_logits(logits, img, h, w, oy, ox, ify, ifx));
+                const float4 y = ld4(y_true + ((img * ho + oy) * wo + ox) * 4);
+                // dL/dp_c = -w_c y_c / clip(p_c) inside the clip interval, 0 outside (App. B.6)
+                float4 dp;
+                dp.x = -cw.x * y.x / fminf(fmaxf(pr.x, KEPS), 1.f - KEPS) * inside(pr.x);
+                dp.y = -cw.y * y.y / fminf(fmaxf(pr.y, KEPS), 1.f - KEPS) * inside(pr.y);
+                dp.z = -cw.z * y.z / fminf(fmaxf(pr.z, KEPS), 1.f - KEPS) * inside(pr.z);
+                dp.w = -cw.w * y.w / fminf(fmaxf(pr.w, KEPS), 1.f - KEPS) * inside(pr.w);
+                const float dot = dp.x * pr.x + dp.y * pr.y + dp.z * pr.z + dp.w * pr.w;
+                const float wgt = wy * wx * loss_scale;
+                acc.x = fmaf(wgt, pr.x * (dp.x - dot), acc.x);
+                acc.y = fmaf(wgt, pr.y * (dp.y - dot), acc.y);
+                acc.z = fmaf(wgt, pr.z * (dp.z - dot), acc.z);
+                acc.w = fmaf(wgt, pr.w * (dp.w - dot), acc.w);
+            }
+        }
+        st4(dlogits + i * 4, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ SSD head gather / softmax
+// forward: out[b][off + r] = view(in)[b][r], r in [0, in_img_elems), channel of element = r % c (float4 granules)
+// reverse: in_grad[b][r] = out_grad[b][off + r]
+__global__ void head_gather_kernel(const float* __restrict__ src, const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                   float* __restrict__ dst, int b, int in_img_elems, int c, int out_off, int out_img_elems, int reverse) {
+    const int per = in_img_elems / 4;
+    const long long total = (long long)b * per;
+    const bool aff = scale != nullptr;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long img = i / per;
+        const int r = (int)(i % per) * 4;
+        const long long dense = img * in_img_elems + r, strided = img * out_img_elems + out_off + r;
+        if (!reverse) {
+            float4 s = f4(0.f), t = f4(0.f);
+            const int c0 = r % c;
+            if (aff) { s = ld4(scale + c0); t = ld4(shift + c0); }
+            st4(dst + strided, view_apply4(ld4(src + dense), s, t, aff, act));
+        } else {
+            st4(dst + dense, ld4(src + strided));
+        }
+    }
+}
+
+__global__ void softmax_rows4_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                     float* __restrict__ out, long long rows) {
+    const bool aff = scale != nullptr;
+    float4 s = f4(0.f), t = f4(0.f);
+    if (aff) { s = ld4(scale); t = ld4(shift); }
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (long long)gridDim.x * blockDim.x)
+        st4(out + i * 4, softmax4(view_apply4(ld4(x + i * 4), s, t, aff, act)));
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssdseg_gap_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, float* out, int n, int hw, int c) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(in != nullptr && in->x != nullptr && ((in->scale == nullptr) == (in->shift == nullptr)), 2);
+    SSDSEG_ARG(out != nullptr, 3);
+    SSDSEG_ARG(n > 0, 4);
+    SSDSEG_ARG(hw > 0, 5);
+    SSDSEG_ARG(c > 0 && c % 4 == 0, 6);
+    const int cv = c / 4;
+    const int bx = cv < 128 ? cv : 128;
+    int by = 512 / bx;
+    if (by > hw) by = hw;
+    if (by < 1) by = 1;
+    SSDSEG_LAUNCH(ctx, 4.0 * ((double)n * hw * c + (double)n * c), 0.0, gap_fwd_kernel, dim3(n, cdiv(cv, bx)), dim3(bx, by),
+                  (size_t)bx * by * sizeof(float4), in->x, in->scale, in->shift, in->act, out, hw, c);
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+int ssdseg_gap_bwd(ssdseg_ctx* ctx, const float* g, float* dx, int n, int hw, int c, int accumulate) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(g != nullptr, 2);
+    SSDSEG_ARG(dx != nullptr, 3);
+    SSDSEG_ARG(n > 0 && hw > 0, 4);
+    SSDSEG_ARG(c > 0 && c % 4 == 0, 6);
+    const long long total = (long long)n * hw * (c / 4);
+    SSDSEG_LAUNCH(ctx, 4.0 * n * hw * c * (accumulate ? 2 : 1), 0.0, gap_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, g, dx, n, hw, c / 4,
+                  accumulate);
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+int ssdseg_bilinear_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, float* out, int ldo, int n, int h, int wdt, int c, int fy,
+                        int fx) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(in != nullptr && in->x != nullptr && ((in->scale == nullptr) == (in->shift == nullptr)), 2);
+    SSDSEG_ARG(ldx >= c && ldx % 4 == 0, 3);
+    SSDSEG_ARG(out != nullptr, 4);
+    SSDSEG_ARG(ldo >= c && ldo % 4 == 0, 5);
+    SSDSEG_ARG(n > 0 && h > 0 && wdt > 0, 6);
+    SSDSEG_ARG(c > 0 && c % 4 == 0, 9);
+    SSDSEG_ARG(fy >= 1 && fx >= 1, 10);
+    const long long total = (long long)n * h * fy * wdt * fx * (c / 4);
+    SSDSEG_LAUNCH(ctx, 4.0 * ((double)n * h * wdt * c + 4.0 * total), 0.0, bilinear_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, in->x,
+                  in->scale, in->shift, in->act, ldx, out, ldo, n, h, wdt, c / 4, fy, fx);
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+int ssdseg_bilinear_bwd(ssdseg_ctx* ctx, const float* g, int ldg, float* dx, int ldx, int n, int h, int wdt, int c, int fy, int fx,
+                        int accumulate) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(g != nullptr, 2);
+    SSDSEG_ARG(ldg >= c && ldg % 4 == 0, 3);
+    SSDSEG_ARG(dx != nullptr, 4);
+    SSDSEG_ARG(ldx >= c && ldx % 4 == 0, 5);
+    SSDSEG_ARG(n > 0 && h > 0 && wdt > 0, 6);
+    SSDSEG_ARG(c > 0 && c % 4 == 0, 9);
+    SSDSEG_ARG(fy >= 1 && fx >= 1, 10);
+    const long long total = (long long)n * h * wdt * (c / 4);
+    SSDSEG_LAUNCH(ctx, 4.0 * ((double)n * h * wdt * c * (1 + fy * fx)), 0.0, bilinear_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, g, ldg,
+                  dx, ldx, n, h, wdt, c / 4, fy, fx, accumulate);
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+int ssdseg_mask_head_fwd(ssdseg_ctx* ctx, const float* logits, int n, int h, int wdt, int c, int fy, int fx, const float* y_true,
+                         const float* class_weights_host, float* prob, float* loss) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(logits != nullptr, 2);
+    SSDSEG_ARG(n > 0 && h > 0 && wdt > 0, 3);
+    SSDSEG_ARG(c == 4, 6);   // the reference itself hard-codes depth 4 (layers.py:204, models.py:250-253)
+    SSDSEG_ARG(fy >= 1 && fx >= 1, 7);
+    SSDSEG_ARG((loss == nullptr) || (y_true != nullptr && class_weights_host != nullptr), 9);
+    float cwh[4] = {0, 0, 0, 0};
+    if (loss) memcpy(cwh, class_weights_host, sizeof(cwh));
+    const long long npix = (long long)h * fy * wdt * fx;
+    int nblk = (int)((npix + 256 * 8 - 1) / (256 * 8));
+    if (nblk > 256) nblk = 256;
+    if (nblk < 1) nblk = 1;
+    float* partial = nullptr;
+    if (loss) {
+        void* ws;
+        int rc = ssdseg_workspace(ctx, (size_t)n * nblk * sizeof(float), &ws);
+        if (rc) return rc;
+        partial = (float*)ws;
+    }
+    SSDSEG_LAUNCH(ctx, 16.0 * n * npix * ((y_true ? 1 : 0) + (prob ? 1 : 0)), 0.0, mask_head_fwd_kernel, dim3(nblk, n), dim3(256), 0, logits, h,
+                  wdt, fy, fx, loss ? y_true : nullptr, make_float4(cwh[0], cwh[1], cwh[2], cwh[3]), prob, partial);
+    SSDSEG_LAUNCH_CHECK();
+    if (loss) {
+        SSDSEG_LAUNCH(ctx, 4.0 * n * nblk, 0.0, mask_loss_final_kernel, dim3(cdiv(n, 64)), dim3(64), 0, partial, nblk, loss, n);
+        SSDSEG_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+int ssdseg_mask_head_bwd(ssdseg_ctx* ctx, const float* logits, int n, int h, int wdt, int c, int fy, int fx, const float* y_true,
+                         const float* class_weights_host, float loss_scale, float* dlogits) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(logits != nullptr, 2);
+    SSDSEG_ARG(n > 0 && h > 0 && wdt > 0, 3);
+    SSDSEG_ARG(c == 4, 6);
+    SSDSEG_ARG(fy >= 1 && fx >= 1, 7);
+    SSDSEG_ARG(y_true != nullptr, 9);
+    SSDSEG_ARG(class_weights_host != nullptr, 10);
+    SSDSEG_ARG(dlogits != nullptr, 12);
+    float cwh[4];
+    memcpy(cwh, class_weights_host, sizeof(cwh));
+    const long long total = (long long)n * h * wdt;
+    SSDSEG_LAUNCH(ctx, 16.0 * n * h * fy * wdt * fx, 0.0, mask_head_bwd_kernel, dim3(ew_blocks(total, 256)), dim3(256), 0, logits, n, h, wdt,
+                  fy, fx, y_true, make_float4(cwh[0], cwh[1], cwh[2], cwh[3]), loss_scale, dlogits);
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+int ssdseg_head_gather(ssdseg_ctx* ctx, const ssdseg_view* in, float* out, int b, int in_img_elems, int c, int out_off_elems,
+                       int out_img_elems, int reverse) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(in != nullptr && in->x != nullptr && ((in->scale == nullptr) == (in->shift == nullptr)), 2);
+    SSDSEG_ARG(out != nullptr, 3);
+    SSDSEG_ARG(b > 0, 4);
+    SSDSEG_ARG(in_img_elems > 0 && in_img_elems % 4 == 0, 5);
+    SSDSEG_ARG(c > 0 && c % 4 == 0 && in_img_elems % c == 0, 6);
+    SSDSEG_ARG(out_off_elems >= 0 && out_off_elems % 4 == 0, 7);
+    SSDSEG_ARG(out_img_elems >= out_off_elems + in_img_elems && out_img_elems % 4 == 0, 8);
+    const long long total = (long long)b * (in_img_elems / 4);
+    SSDSEG_LAUNCH(ctx, 8.0 * b * in_img_elems, 0.0, head_gather_kernel, dim3(ew_blocks(total)), dim3(256), 0, in->x, in->scale, in->shift,
+                  in->act, out, b, in_img_elems, c, out_off_elems, out_img_elems, reverse);
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+int ssdseg_softmax_rows(ssdseg_ctx* ctx, const ssdseg_view* in, float* out, int rows, int c) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(in != nullptr && in->x != nullptr && ((in->scale == nullptr) == (in->shift == nullptr)), 2);
+    SSDSEG_ARG(out != nullptr, 3);
+    SSDSEG_ARG(rows > 0, 4);
+    SSDSEG_ARG(c == 4, 5);
+    SSDSEG_LAUNCH(ctx, 32.0 * rows, 0.0, softmax_rows4_kernel, dim3(ew_blocks(rows)), dim3(256), 0, in->x, in->scale, in->shift, in->act, out,
+                  (long long)rows);
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

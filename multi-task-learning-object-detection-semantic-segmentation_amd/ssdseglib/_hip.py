@@ -85,12 +85,14 @@ _SIGNATURES = {
     "ssdseg_gap_bwd": [_vp, _vp, _vp, _i, _i, _i, _i],
     "ssdseg_bilinear_fwd": [_vp, _VP, _i, _vp, _i, _i, _i, _i, _i, _i, _i],
     "ssdseg_bilinear_bwd": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i],
-    "ssdseg_mask_head_fwd": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
-    "ssdseg_mask_head_bwd": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _f, _vp],
+    "ssdseg_mask_head_fwd": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, C.POINTER(_f), _vp, _vp],
+    "ssdseg_mask_head_bwd": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, C.POINTER(_f), _f, _vp],
+    "ssdseg_head_gather": [_vp, _VP, _vp, _i, _i, _i, _i, _i, _i],
     "ssdseg_softmax_rows": [_vp, _VP, _vp, _i, _i],
     "ssdseg_det_loss": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
     "ssdseg_topk_mask": [_vp, _vp, _i, _i, _vp],
-    "ssdseg_dice_loss": [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp],
+    "ssdseg_dice_loss": [_vp, _vp, _vp, _i, _i, _i, C.POINTER(_f), _i, _vp],
+    "ssdseg_act_bwd": [_vp, _vp, _i, _vp, _i, _i, _i, _i],
     "ssdseg_encode_targets": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _f, C.POINTER(_f), _vp, _vp, _vp],
     "ssdseg_decode_boxes": [_vp, _vp, _vp, _i, _i, C.POINTER(_f), _vp],
     "ssdseg_combined_nms": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp],

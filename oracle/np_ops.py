@@ -231,6 +231,22 @@ def maxpool3x3s2_fwd(x):
     return out
 
 
+def maxpool3x3s2_bwd(x, g):
+    """gradient of MaxPooling2D(3, 2, 'same'): routed to the first maximum of each window (row-major scan)."""
+    n, h, w, c = x.shape
+    ho, pt, pb = same_pad(h, 3, 2)
+    wo, pl, pr = same_pad(w, 3, 2)
+    xp = np.full((n, h + pt + pb, w + pl + pr, c), -np.inf, dtype=x.dtype)
+    xp[:, pt:pt + h, pl:pl + w] = x
+    dxp = np.zeros_like(xp)
+    taps = np.stack([_tap(xp, kh, kw, ho, wo, 2, 1) for kh in range(3) for kw in range(3)], axis=0)  # (9, n, ho, wo, c)
+    first = taps.argmax(axis=0)                                                                       # first maximum
+    for t in range(9):
+        kh, kw = divmod(t, 3)
+        _tap(dxp, kh, kw, ho, wo, 2, 1)[...] += g * (first == t)
+    return dxp[:, pt:pt + h, pl:pl + w]
+
+
 def channel_shuffle(x, groups=2):
     """Reshape(h,w,g,c/g) -> Permute(1,2,4,3) -> Reshape (models.py:497-503)."""
     n, h, w, c = x.shape
