@@ -229,6 +229,10 @@ __global__ void __launch_bounds__(256) dice_partial_kernel(const float* __restri
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) {
         const long long o = ((long long)img * hw + i) * 4;
         const float4 a = ld4(y + o), b = ld4(p + o);
+        if (squared == 2) {   // weighted cross-entropy on probabilities (losses.py:294-299): acc[c] = -sum y*log(clip p)
+            acc[0] -= a.x * logf(clipf(b.x)); acc[1] -= a.y * logf(clipf(b.y)); acc[2] -= a.z * logf(clipf(b.z)); acc[3] -= a.w * logf(clipf(b.w));
+            continue;
+        }
         acc[0] += a.x * b.x; acc[1] += a.y * b.y; acc[2] += a.z * b.z; acc[3] += a.w * b.w;
         if (squared) { acc[4] += a.x * a.x + b.x * b.x; acc[5] += a.y * a.y + b.y * b.y; acc[6] += a.z * a.z + b.z * b.z; acc[7] += a.w * a.w + b.w * b.w; }
         else { acc[4] += a.x + b.x; acc[5] += a.y + b.y; acc[6] += a.z + b.z; acc[7] += a.w + b.w; }
@@ -238,7 +242,7 @@ __global__ void __launch_bounds__(256) dice_partial_kernel(const float* __restri
         for (int k = 0; k < 8; ++k) partial[((long long)img * gridDim.x + blockIdx.x) * 8 + k] = acc[k];
 }
 
-__global__ void dice_finish_kernel(const float* __restrict__ partial, int nblk, int n, float4 cw, float* __restrict__ loss) {
+__global__ void dice_finish_kernel(const float* __restrict__ partial, int nblk, int n, float4 cw, int mode, float* __restrict__ loss) {
     const int img = blockIdx.x * blockDim.x + threadIdx.x;
     if (img >= n) return;
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -246,7 +250,7 @@ __global__ void dice_finish_kernel(const float* __restrict__ partial, int nblk, 
         for (int k = 0; k < 8; ++k) s[k] += partial[((long long)img * nblk + q) * 8 + k];
     const float w[4] = {cw.x, cw.y, cw.z, cw.w};
     float l = 0.f;
-    for (int c = 0; c < 4; ++c) l += (1.f - (2.f * s[c] + KEPS) / (s[4 + c] + KEPS)) * w[c];
+    for (int c = 0; c < 4; ++c) l += (mode == 2 ? s[c] : (1.f - (2.f * s[c] + KEPS) / (s[4 + c] + KEPS))) * w[c];
     loss[img] = l;
 }
 
@@ -323,7 +327,7 @@ int ssdseg_dice_loss(ssdseg_ctx* ctx, const float* y_true, const float* p, int n
     SSDSEG_LAUNCH(ctx, 32.0 * n * hw, 0.0, dice_partial_kernel, dim3(nblk, n), dim3(256), 0, y_true, p, hw, squared, (float*)ws);
     SSDSEG_LAUNCH_CHECK();
     SSDSEG_LAUNCH(ctx, 0.0, 0.0, dice_finish_kernel, dim3(cdiv(n, 64)), dim3(64), 0, (const float*)ws, nblk, n,
-                  make_float4(class_weights_host[0], class_weights_host[1], class_weights_host[2], class_weights_host[3]), loss);
+                  make_float4(class_weights_host[0], class_weights_host[1], class_weights_host[2], class_weights_host[3]), squared, loss);
     SSDSEG_LAUNCH_CHECK();
     return 0;
 }

@@ -5,3 +5,7 @@ from . import boxes
 from . import blocks
 from . import layers
 from . import models
+from . import losses
+from . import metrics
+from . import datacoder
+from . import optimizers

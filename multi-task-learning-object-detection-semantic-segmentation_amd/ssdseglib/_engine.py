@@ -372,11 +372,10 @@ class DetLossOp(Op):
 
     def fwd(self):
         p = self.probs
-        if not self.e.training:
-            return
         assert self.w_conf == self.w_loc, "per-output loss weights must match for the fused detection loss"
+        tr = self.e.training
         self.e.ctx.call("ssdseg_det_loss", self.y_labels, p.buf, self.y_boxes, self.boxes.buf, p.n, p.h * p.w, p.c, self.w_conf / p.n,
-                        self.conf_loss, self.loc_loss, self.logits.grad, self.boxes.grad, None)
+                        self.conf_loss, self.loc_loss, self.logits.grad if tr else None, self.boxes.grad if tr else None, None)
 
     def bwd(self):
         self.logits.gwritten = True
@@ -811,11 +810,91 @@ class Engine:
         shp = self.model.outputs[index].shape
         return arr.reshape((s.n,) + tuple(shp[1:]))
 
+    # ------------------------------------------------------------------ training step (Keras train_step stand-in)
+    def configure_losses(self, loss: dict, loss_weights: dict):
+        """bind the compiled losses to the fused loss ops (reference NB03#cell14: cross_entropy(w) / confidence_loss /
+        localization_loss, weights 1/1/1; Keras reduces each (B,) loss by its batch mean)"""
+        from . import losses as LS
+        self._loss_names = []
+        b = self.batch
+        for t in self.model.outputs:
+            name = t.layer.name
+            fn = loss.get(name)
+            if fn is None:
+                continue
+            w = float(loss_weights.get(name, 1.0))
+            v = self.vals[id(t)]
+            if "mask_head" in v.meta:
+                if getattr(fn, "loss_kind", None) != "cross_entropy":
+                    raise NotImplementedError("the fused mask head trains with ssdseglib.losses.cross_entropy(weights); dice losses are "
+                                              "available as standalone functions")
+                op: MaskHeadOp = v.meta["mask_head"]
+                s = op.logits.store
+                op.y_true = self.ctx.empty((b, s.h * op.fy, s.w * op.fx, s.c))
+                op.class_weights = (C.c_float * 4)(*[float(x) for x in fn.classes_weights])
+                op.loss = self.ctx.empty(b)
+                op.loss_scale = w / b
+                self._loss_names.append((name, op, "mask"))
+            elif fn is LS.confidence_loss or fn is LS.localization_loss:
+                det = self.loss_ops.get("det")
+                if det is None:
+                    labels_v = next(self.vals[id(o)] for o in self.model.outputs if "logits" in self.vals[id(o)].meta)
+                    boxes_v = next(self.vals[id(o)] for o in self.model.outputs if self.vals[id(o)].meta.get("head_concat"))
+                    det = DetLossOp(self, labels_v.meta["logits"], labels_v.store, boxes_v.store)
+                    a = labels_v.store.h * labels_v.store.w
+                    det.y_labels = self.ctx.empty((b, a, labels_v.store.c))
+                    det.y_boxes = self.ctx.empty((b, a, 4))
+                    self.loss_ops["det"] = det
+                    self._emit(det)
+                if fn is LS.confidence_loss:
+                    det.w_conf = w
+                    self._loss_names.append((name, det, "conf"))
+                else:
+                    det.w_loc = w
+                    self._loss_names.append((name, det, "loc"))
+            else:
+                raise NotImplementedError(f"loss for output {name}: only the ssdseglib.losses functions are supported")
+
+    def set_targets(self, targets: dict):
+        for name, op, kind in self._loss_names:
+            y = targets[name]
+            dst = op.y_true if kind == "mask" else (op.y_labels if kind == "conf" else op.y_boxes)
+            if isinstance(y, H.DeviceBuffer):
+                if y.ptr != dst.ptr:
+                    dst.copy_from(y)
+            else:
+                dst.upload(np.ascontiguousarray(y, np.float32))
+
+    def losses(self) -> Dict[str, float]:
+        """batch means of the per-sample losses, Keras naming (`loss`, `<output>_loss`)"""
+        out, total = {}, 0.0
+        for name, op, kind in self._loss_names:
+            buf = op.loss if kind == "mask" else (op.conf_loss if kind == "conf" else op.loc_loss)
+            w = op.loss_scale * self.batch if kind == "mask" else (op.w_conf if kind == "conf" else op.w_loc)
+            v = float(buf.download().mean())
+            out[f"{name}_loss"] = v
+            total += w * v
+        out["loss"] = total
+        return out
+
+    def train_step(self, images=None, targets=None, optimizer=None, allreduce=None, world=1):
+        if images is not None:
+            self.set_input(images)
+        if targets is not None:
+            self.set_targets(targets)
+        self.forward()
+        self.backward()
+        if allreduce is not None:
+            allreduce()
+        o = optimizer
+        self.adam_step(lr=o.learning_rate, beta1=o.beta_1, beta2=o.beta_2, eps=o.epsilon, grad_scale=1.0 / world) if o is not None \
+            else self.adam_step(grad_scale=1.0 / world)
+
     def adam_step(self, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
-        self.adam_step_count += 1
         P = self.P
+        P["step"] = P.get("step", 0) + 1          # shared by every engine (batch size) of the same model
         self.ctx.call("ssdseg_adam_step", P["params"], P["grads"], P["adam_m"], P["adam_v"], C.c_size_t(P["n_tr"]), lr, beta1, beta2, eps,
-                      self.adam_step_count, grad_scale)
+                      P["step"], grad_scale)
 
 
 _default_ctx: Optional[H.Context] = None
@@ -837,5 +916,112 @@ def engine_for(model: K.Model, batch_size: int, training: bool) -> Engine:
     cache = model.__dict__.setdefault("_engines", {})
     key = (int(batch_size), bool(training))
     if key not in cache:
-        cache[key] = Engine(model, batch_size, training)
+        eng = Engine(model, batch_size, training)
+        if training:
+            comp = model._compiled
+            if comp is None:
+                raise RuntimeError("call model.compile(optimizer=..., loss=...) before fit / train_on_batch")
+            eng.configure_losses(comp["loss"], comp["loss_weights"])
+        cache[key] = eng
     return cache[key]
+
+
+def eval_engine_for(model: K.Model, batch_size: int) -> Engine:
+    """inference-mode engine that also evaluates the compiled losses (validation_data of fit)"""
+    cache = model.__dict__.setdefault("_engines", {})
+    key = (int(batch_size), "eval")
+    if key not in cache:
+        eng = Engine(model, batch_size, False)
+        eng.configure_losses(model._compiled["loss"], model._compiled["loss_weights"])
+        cache[key] = eng
+    return cache[key]
+
+
+# ---------------------------------------------------------------------------------------------- Keras-like entry points
+def _postprocess(model: K.Model, eng: Engine, index: int) -> np.ndarray:
+    out = eng.output(index)
+    v = eng.output_vals[index]
+    nms = v.meta.get("nms")
+    if nms is not None and nms.suppress_background_boxes:
+        # quirk Q7 (reference layers.py:165-166): boolean_mask drops the batch axis
+        out = out.reshape(-1, 6)
+        out = out[out[:, 0] > 0]
+    return out
+
+
+def run_forward(model: K.Model, x, training: bool = False) -> List[np.ndarray]:
+    """model(x, training=False) -> list of output arrays (NB03#cell31)"""
+    x = np.asarray(x, np.float32)
+    if x.ndim == 3:
+        x = x[None]
+    eng = engine_for(model, x.shape[0], False)
+    eng.set_input(x)
+    eng.forward()
+    return [_postprocess(model, eng, i) for i in range(len(model.outputs))]
+
+
+def _batches(data):
+    """accepts an iterable of batches: x, (x,), (x, y) with y a dict keyed by output name"""
+    for item in data:
+        if isinstance(item, (tuple, list)):
+            yield item[0], (item[1] if len(item) > 1 else None)
+        else:
+            yield item, None
+
+
+def run_predict(model: K.Model, data) -> List[np.ndarray]:
+    """model.predict(dataset) -> outputs concatenated over the batches (NB03#cell25)"""
+    if isinstance(data, np.ndarray):
+        data = [data[i:i + 16] for i in range(0, data.shape[0], 16)]
+    chunks: List[List[np.ndarray]] = []
+    for x, _ in _batches(data):
+        chunks.append(run_forward(model, x))
+    return [np.concatenate([c[i] for c in chunks], axis=0) for i in range(len(model.outputs))]
+
+
+def run_train_on_batch(model: K.Model, x, y) -> Dict[str, float]:
+    x = np.asarray(x, np.float32)
+    eng = engine_for(model, x.shape[0], True)
+    eng.train_step(x, y, optimizer=model._compiled.get("optimizer"))
+    return eng.losses()
+
+
+class History:
+    def __init__(self):
+        self.history: Dict[str, List[float]] = {}
+        self.epoch: List[int] = []
+
+
+def run_fit(model: K.Model, data, epochs=1, validation_data=None, verbose=0) -> History:
+    """model.fit(ds, epochs, validation_data, verbose) (NB03#cell16): the last partial batch is kept (its own batch
+    statistics and mining pool); per-epoch means weighted by batch size, Keras history keys."""
+    hist = History()
+    for epoch in range(epochs):
+        sums: Dict[str, float] = {}
+        seen = 0
+        for x, y in _batches(data):
+            logs = run_train_on_batch(model, x, y)
+            n = np.asarray(x).shape[0]
+            for k, v in logs.items():
+                sums[k] = sums.get(k, 0.0) + v * n
+            seen += n
+        logs = {k: v / max(seen, 1) for k, v in sums.items()}
+        if validation_data is not None:
+            vs: Dict[str, float] = {}
+            vseen = 0
+            for x, y in _batches(validation_data):
+                x = np.asarray(x, np.float32)
+                eng = eval_engine_for(model, x.shape[0])   # moving statistics, no gradient buffers (Keras test_step)
+                eng.set_input(x)
+                eng.set_targets(y)
+                eng.forward()
+                for k, v in eng.losses().items():
+                    vs[k] = vs.get(k, 0.0) + v * x.shape[0]
+                vseen += x.shape[0]
+            logs.update({f"val_{k}": v / max(vseen, 1) for k, v in vs.items()})
+        for k, v in logs.items():
+            hist.history.setdefault(k, []).append(v)
+        hist.epoch.append(epoch)
+        if verbose:
+            print(f"Epoch {epoch + 1}/{epochs} - " + " - ".join(f"{k}: {v:.4f}" for k, v in logs.items()))
+    return hist

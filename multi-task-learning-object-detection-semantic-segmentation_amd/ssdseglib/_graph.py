@@ -84,9 +84,11 @@ class Layer:
         self._engine_sync = None  # set by the engine: (pull weights from device, push weights to device)
 
     # -- functional call
-    def __call__(self, inputs, *args, **kwargs):
-        ins = list(inputs) if isinstance(inputs, (list, tuple)) else [inputs]
-        ins += [a for a in args if isinstance(a, KTensor)]
+    def __call__(self, *args, **kwargs):
+        ins = []
+        for a in args:
+            ins += list(a) if isinstance(a, (list, tuple)) else [a]
+        ins = [a for a in ins if isinstance(a, KTensor)]
         ins += [v for v in kwargs.values() if isinstance(v, KTensor)]
         if self.inbound:
             raise ValueError(f"layer {self.name} is already connected (layer sharing is not supported)")
