@@ -1,20 +1,23 @@
 #!/usr/bin/env python3
-"""bench.py -- images/sec of the ssdseglib hot path on MI355X (contract: see the task statement / DESIGN.md).
+"""bench.py -- images/sec of the ssdseglib hot path on MI355X (contract: task statement / DESIGN.md "Measurement").
 
-Workload at N=1 = BASELINE.json configs[1]: MobileNetV2 backbone (blocks 0..16, reference models.py:169-215)
-forward + backward at batch 32, 480x640x3, fp32, with synthetic upstream gradients on the three tensors the heads
-tap (`backbone-block16-project-batchnorm`, `backbone-block3-expand-relu6`, `backbone-block13-expand-relu6`), followed
-by the gradient all-reduce (N>1) and the Adam update.  `--workload full` runs configs[2] (whole multi-task train step).
+Workloads (BASELINE.json `configs`):
+  backbone (default, configs[1], the configuration the metric is quoted on at N=1):
+      MobileNetV2 backbone blocks 0..16 (reference models.py:169-215) forward + backward at batch 32/GPU, 480x640x3,
+      fp32, synthetic upstream gradients on the three tensors the heads tap (`backbone-block16-project-batchnorm`,
+      `backbone-block3-expand-relu6`, `backbone-block13-expand-relu6`), gradient all-reduce (N>1), Adam.
+  full (configs[2]/[3]): the whole MobileNetV2-SSDLite-DeepLabV3+ train step: anchor encode -> forward -> 3 losses
+      (weighted CE, confidence with hard-negative mining, localization) -> backward -> all-reduce -> Adam.
 
-One process per GPU: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`; torch is used only as
-plumbing (process group = RCCL over xGMI, gradient bucket tensor); all compute goes through libssdseg_hip.so.
-Each rank works on its own shard of the global batch (weak scaling), one collective per step (flat fp32 gradient
-bucket, sum then x 1/N inside Adam).
+One process per GPU (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`); torch is plumbing only
+(RCCL process group + the gradient-bucket tensor); every kernel is ours (libssdseg_hip.so).  Weak scaling: each rank
+owns a 32-image shard, one collective per step.
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed inside the C library on the launch
-stream) and `cpu_baseline` (NumPy oracle of the same step on the host cores, bounded sample).
+Rank 0 prints ONE JSON line with `roofline` (dominant kernel symbol; durations from HIP events recorded around every
+launch of the timed region, on the launch stream, inside the C library) and `cpu_baseline` (NumPy oracle, bounded sample).
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -26,21 +29,54 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(REPO, "multi-task-learning-object-detection-semantic-segmentation_amd"))
 sys.path.insert(0, REPO)
 
-HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s is the measured float4-copy ceiling
-MFMA_F32_PEAK_TFLOPS = 157.3  # fp32-input MFMA dense peak
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s is the measured float4-copy ceiling
+MFMA_F32_PEAK_TFLOPS = 157.3   # fp32-input MFMA dense peak
 
 TAPS = ['backbone-block16-project-batchnorm', 'backbone-block3-expand-relu6', 'backbone-block13-expand-relu6']
 IMAGE_SHAPE = (480, 640, 3)
+CLASS_WEIGHTS = (0.05, 0.575, 0.135, 0.24)     # NB03#cell10
+STDS = (0.1, 0.1, 0.2, 0.2)
+
+
+def default_boxes():
+    import ssdseglib
+    b = ssdseglib.boxes.DefaultBoundingBoxes(feature_maps_shapes=((30, 40), (15, 20), (8, 10), (4, 5)),
+                                             centers_padding_from_borders_percentage=(0.025, 0.05, 0.075, 0.1), boxes_scales=(0.15, 0.95),
+                                             additional_square_box=True)                     # NB03#cell6
+    b.rescale_boxes_coordinates(image_shape=IMAGE_SHAPE[:2])
+    return b
+
+
+def build_models(seed=1993):
+    """-> (boxes, builder, full training model, backbone-only model) for the NB03 configuration"""
+    import ssdseglib
+    from ssdseglib import _graph as K
+    K.set_seed(seed)
+    boxes = default_boxes()
+    builder = ssdseglib.models.MobileNetV2SsdSegBuilder(
+        input_image_shape=IMAGE_SHAPE, number_of_boxes_per_point=[6, 6, 6, 6], number_of_classes=4,
+        center_x_boxes_default=boxes.get_boxes_coordinates_center_x('ssd'), center_y_boxes_default=boxes.get_boxes_coordinates_center_y('ssd'),
+        width_boxes_default=boxes.get_boxes_coordinates_width('ssd'), height_boxes_default=boxes.get_boxes_coordinates_height('ssd'),
+        standard_deviations_centroids_offsets=STDS)
+    return boxes, builder
 
 
 def build_backbone_model():
-    import ssdseglib
     from ssdseglib import _graph as K
-    K.set_seed(1993)
-    dummy = np.zeros(4, np.float32)
-    b = ssdseglib.models.MobileNetV2SsdSegBuilder(IMAGE_SHAPE, 6, 4, dummy, dummy, dummy, dummy, (0.1, 0.1, 0.2, 0.2))
+    _, b = build_models()
     inp = b._mobilenetv2_backbone()
     return K.Model(inputs=inp, outputs=[b._layers[n] for n in TAPS])
+
+
+def build_full_model():
+    import ssdseglib
+    boxes, b = build_models()
+    model = b.get_model_for_training('deeplabv3plus', 'ssdlite', segmentation_dilation_rates=(3, 6, 12))     # NB03#cell12
+    model.compile(optimizer=ssdseglib.optimizers.Adam(learning_rate=1e-4),
+                  loss={'output-mask': ssdseglib.losses.cross_entropy(classes_weights=CLASS_WEIGHTS),
+                        'output-labels': ssdseglib.losses.confidence_loss, 'output-boxes': ssdseglib.losses.localization_loss},
+                  loss_weights={'output-mask': 1.0, 'output-labels': 1.0, 'output-boxes': 1.0})                # NB03#cell14
+    return boxes, model
 
 
 def synthetic_images(batch, seed):
@@ -48,22 +84,40 @@ def synthetic_images(batch, seed):
     return rng.integers(0, 256, (batch,) + IMAGE_SHAPE, dtype=np.uint8).astype(np.float32)
 
 
+def synthetic_ground_truth(batch, seed, gmax=8):
+    """1..8 boxes/image, labels 1..3, log-uniform sizes 24..400 px; masks rasterised from the boxes"""
+    rng = np.random.default_rng(seed)
+    h, w = IMAGE_SHAPE[:2]
+    gt = np.zeros((batch, gmax, 5), np.float32)
+    cnt = np.zeros(batch, np.int32)
+    mask = np.zeros((batch, h, w), np.int64)
+    for i in range(batch):
+        g = int(rng.integers(1, gmax + 1))
+        cnt[i] = g
+        bw = np.minimum(np.exp(rng.uniform(np.log(24), np.log(400), g)), w - 2)
+        bh = np.minimum(np.exp(rng.uniform(np.log(24), np.log(400), g)), h - 2)
+        x0 = rng.uniform(0, w - 1 - bw)
+        y0 = rng.uniform(0, h - 1 - bh)
+        lab = rng.integers(1, 4, g)
+        gt[i, :g] = np.stack([lab, x0, y0, x0 + bw, y0 + bh], axis=1)
+        for l, xa, ya, ww, hh in zip(lab, x0, y0, bw, bh):
+            mask[i, int(ya):int(ya + hh) + 1, int(xa):int(xa + ww) + 1] = l
+    return gt, cnt, np.eye(4, dtype=np.float32)[mask]
+
+
 class BackboneStep:
     """configs[1]: fwd + bwd (+ all-reduce) + Adam of the MobileNetV2 backbone on a resident batch"""
+    workload = ("BASELINE.json configs[1]: MobileNetV2 backbone-only fwd+bwd(+all-reduce)+Adam, batch 32/GPU, 480x640x3, synthetic "
+                "upstream gradients on the 3 head taps")
 
-    def __init__(self, ctx, batch, rank, world, grad_bucket=None, allreduce=None):
+    def __init__(self, ctx, batch, rank, reducer, grad_bucket=None):
         from ssdseglib import _engine as E
         self.model = build_backbone_model()
         self.eng = E.Engine(self.model, batch, training=True, ctx=ctx, grad_bucket=grad_bucket)
-        self.ctx, self.world, self.allreduce = ctx, world, allreduce
+        self.reducer = reducer
         self.eng.set_input(synthetic_images(batch, 1993 + rank))
         rng = np.random.default_rng(7 + rank)
-        self.seeds = []
-        for i, t in enumerate(self.model.outputs):
-            shape = (batch,) + tuple(t.shape[1:])
-            g = (rng.standard_normal(shape, dtype=np.float32) * np.float32(1e-3))
-            self.seeds.append(ctx.array(g))
-        self.batch = batch
+        self.seeds = [ctx.array(rng.standard_normal((batch,) + tuple(t.shape[1:]), dtype=np.float32) * np.float32(1e-3)) for t in self.model.outputs]
 
     def __call__(self):
         e = self.eng
@@ -71,22 +125,66 @@ class BackboneStep:
         for i, g in enumerate(self.seeds):
             e.seed_output_grad(i, g)
         e.backward_from_outputs()
-        if self.allreduce is not None:
-            self.allreduce()
-        e.adam_step(lr=1e-4, grad_scale=1.0 / self.world)
+        if self.reducer is not None:
+            self.reducer()
+        e.adam_step(lr=1e-4, grad_scale=self.reducer.scale if self.reducer is not None else 1.0)
 
 
-def cpu_baseline_backbone(sample_batch=1):
-    """NumPy oracle of the same step (fwd + bwd + Adam) on the host cores, bounded sample."""
-    from oracle.np_model import NpModel
+class FullStep:
+    """configs[2]: encode targets -> forward -> 3 losses -> backward (-> all-reduce) -> Adam"""
+    workload = ("BASELINE.json configs[2]: full MobileNetV2-SSDLite-DeepLabV3+ train step (anchor encode + fwd + weighted CE / "
+                "confidence+mining / localization losses + bwd (+all-reduce) + Adam), batch 32/GPU, 480x640x3, 9600 anchors, 4 classes")
+
+    def __init__(self, ctx, batch, rank, reducer, grad_bucket=None):
+        from ssdseglib import _engine as E
+        boxes, self.model = build_full_model()
+        self.eng = E.Engine(self.model, batch, training=True, ctx=ctx, grad_bucket=grad_bucket)
+        self.eng.configure_losses(self.model._compiled["loss"], self.model._compiled["loss_weights"])
+        self.reducer, self.ctx, self.batch = reducer, ctx, batch
+        self.eng.set_input(synthetic_images(batch, 1993 + rank))
+        gt, cnt, mask = synthetic_ground_truth(batch, 11 + rank)
+        self.gt, self.cnt, self.gmax = ctx.array(gt), ctx.array(cnt), gt.shape[1]
+        self.anchors = ctx.array(boxes.get_boxes_coordinates_corners('ssd'))
+        self.det = self.eng.loss_ops["det"]
+        self.eng.set_targets({'output-mask': mask, 'output-labels': self.det.y_labels, 'output-boxes': self.det.y_boxes})
+        self.stds = (C.c_float * 4)(*STDS)
+
+    def __call__(self):
+        e = self.eng
+        self.ctx.call("ssdseg_encode_targets", self.anchors, 9600, self.gt, self.cnt, self.batch, self.gmax, 4, 0.525, self.stds,
+                      self.det.y_labels, self.det.y_boxes, None)
+        e.forward()
+        e.backward()
+        if self.reducer is not None:
+            self.reducer()
+        e.adam_step(lr=1e-4, grad_scale=self.reducer.scale if self.reducer is not None else 1.0)
+
+
+def cpu_baseline(workload, sample_batch=1):
+    """NumPy oracle of the same step on the host cores, bounded sample (kind "port": TensorFlow cannot run here)."""
     from oracle import np_ops as O
-    model = build_backbone_model()
+    from oracle.np_model import NpModel
     x = synthetic_images(sample_batch, 1993)
-    ref = NpModel(model, dtype=np.float32)
     rng = np.random.default_rng(7)
-    t0 = time.perf_counter()
-    outs = ref.forward(x, training=True)
-    gouts = [(rng.standard_normal(o.shape, dtype=np.float32) * np.float32(1e-3)) for o in outs]
+    if workload == "backbone":
+        model = build_backbone_model()
+        ref = NpModel(model, dtype=np.float32)
+        t0 = time.perf_counter()
+        outs = ref.forward(x, training=True)
+        gouts = [(rng.standard_normal(o.shape, dtype=np.float32) * np.float32(1e-3)) for o in outs]
+    else:
+        boxes, model = build_full_model()
+        gt, cnt, mask = synthetic_ground_truth(sample_batch, 11)
+        ref = NpModel(model, dtype=np.float32)
+        corners = boxes.get_boxes_coordinates_corners('ssd')
+        t0 = time.perf_counter()
+        enc = [O.encode_targets(corners, gt[i, :cnt[i]], 4, 0.525, STDS) for i in range(sample_batch)]
+        y_labels, y_boxes = np.stack([e[0] for e in enc]), np.stack([e[1] for e in enc])
+        p_mask, p_labels, p_boxes = ref.forward(x, training=True)
+        _, dmask = O.cross_entropy_loss(mask, p_mask, np.asarray(CLASS_WEIGHTS, np.float32))
+        _, dconf, _ = O.confidence_loss(y_labels, p_labels)
+        _, dloc = O.localization_loss(y_boxes, p_boxes)
+        gouts = [dmask / sample_batch, dconf / sample_batch, dloc / sample_batch]
     grads = ref.backward(gouts)
     for lname, gs in grads.items():
         for wname, g in gs.items():
@@ -98,9 +196,10 @@ def cpu_baseline_backbone(sample_batch=1):
         threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
     except Exception:
         threads = os.cpu_count() or 1
-    return dict(value=sample_batch / dt, unit="images/sec", cores=int(threads), kind="port",
-                sample=f"{sample_batch} image(s) 480x640 fwd+bwd+Adam of the same backbone through the NumPy oracle (CPU restatement of "
-                       f"ssdseglib, not TensorFlow); BLAS matmuls on {threads} threads, elementwise passes on 1; {dt:.1f} s")
+    return dict(value=round(sample_batch / dt, 4), unit="images/sec", cores=int(threads), kind="port",
+                sample=f"{sample_batch} image(s) 480x640, the same {workload} step (fwd+bwd+Adam) through the NumPy oracle -- a CPU "
+                       f"restatement of ssdseglib, not TensorFlow (not installable here); BLAS matmuls on {threads} threads, elementwise "
+                       f"passes on 1; {dt:.1f} s")
 
 
 def main():
@@ -109,46 +208,36 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
-    ap.add_argument("--workload", default="backbone", choices=["backbone"])
+    ap.add_argument("--workload", default="backbone", choices=["backbone", "full"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events in the timed region")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs one process per GPU: launch with "
-                  f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py ...`", file=sys.stderr)
-            sys.exit(2)
-        args.gpus = world
-
     from ssdseglib import _hip as H
+    from ssdseglib import _parallel as P
+    rank, local_rank, world = P.env_world()
+    if world == 1 and args.gpus > 1:
+        print(f"bench.py: --gpus {args.gpus} needs one process per GPU: launch with `python -m torch.distributed.run --nnodes=1 "
+              f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...`", file=sys.stderr)
+        sys.exit(2)
+
     dist = None
+    reducer = None
     grad_bucket = None
-    allreduce = None
     if world > 1:
         import torch
-        import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        stream = torch.cuda.current_stream().cuda_stream      # our kernels and RCCL order on torch's current stream
-        ctx = H.Context(local_rank, stream=stream)
+        dist = P.init_process_group(backend="nccl", device_index=local_rank)
+        # our kernels and the RCCL collective are ordered on torch's current stream (borrowed, not owned, by the ctx)
+        ctx = H.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+        model_for_count = build_backbone_model() if args.workload == "backbone" else build_full_model()[1]
+        n_params = sum(int(l.weights[w].size) for l in model_for_count.layers for w in l.trainable_names)
+        bucket_t = torch.zeros(n_params, dtype=torch.float32, device=f"cuda:{local_rank}")
+        grad_bucket = ctx.borrow(bucket_t.data_ptr(), (n_params,), np.float32, owner=bucket_t)
+        reducer = P.GradientAllReduce(bucket_t)
     else:
         ctx = H.Context(local_rank)
 
-    if world > 1:
-        # the flat gradient bucket is a torch tensor (so RCCL can reduce it in place); the library sees a raw pointer
-        n_params = sum(int(l.weights[w].size) for l in build_backbone_model().layers for w in l.trainable_names)
-        bucket_t = torch.zeros(n_params, dtype=torch.float32, device=f"cuda:{local_rank}")
-        grad_bucket = ctx.borrow(bucket_t.data_ptr(), (n_params,), np.float32, owner=bucket_t)
-
-        def allreduce():
-            dist.all_reduce(bucket_t, op=dist.ReduceOp.SUM)
-
-    step = BackboneStep(ctx, args.batch, rank, world, grad_bucket, allreduce)
+    step = (BackboneStep if args.workload == "backbone" else FullStep)(ctx, args.batch, rank, reducer, grad_bucket)
 
     def barrier():
         ctx.sync()
@@ -185,10 +274,8 @@ def main():
             "metric": "images/sec (fwd+bwd, 480x640)", "value": round(value, 2), "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: MobileNetV2 backbone-only fwd+bwd(+all-reduce)+Adam, batch 32/GPU, 480x640x3, "
-                                   "synthetic upstream gradients on the 3 head taps",
-                       "global_batch": args.batch * world, "per_gpu_batch": args.batch, "parallelism": f"dp{world}",
-                       "device": ctx.device_name()},
+            "config": {"workload": step.workload, "global_batch": args.batch * world, "per_gpu_batch": args.batch,
+                       "parallelism": f"dp{world}", "device": ctx.device_name()},
         }
         if report:
             total_ms = sum(v["ms"] for v in report.values())
@@ -206,14 +293,14 @@ def main():
                 "share_of_kernel_time": round(dom["ms"] / total_ms, 4),
                 "algorithmic_bytes_per_launch": dom["bytes"] / dom["count"], "flops_per_launch": dom["flops"] / dom["count"],
             }
-            top = sorted(report.items(), key=lambda kv: -kv[1]["ms"])[:12]
+            top = sorted(report.items(), key=lambda kv: -kv[1]["ms"])[:14]
             out["kernels"] = [
                 {"kernel": k, "launches": v["count"], "ms_per_step": round(v["ms"] / args.steps, 4),
                  "GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0.0,
                  "TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0.0} for k, v in top]
             out["kernel_ms_per_step"] = round(total_ms / args.steps, 3)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_backbone(1)
+            out["cpu_baseline"] = cpu_baseline(args.workload, 1)
         print(json.dumps(out), flush=True)
 
     if dist is not None:

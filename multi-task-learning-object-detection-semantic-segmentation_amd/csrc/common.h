@@ -25,6 +25,16 @@ struct ssdseg_ctx {
 void ssdseg_timing_begin(ssdseg_ctx* ctx, const char* kernel, double bytes, double flops);
 void ssdseg_timing_end(ssdseg_ctx* ctx);
 
+// stable copy of a kernel-symbol string built at run time (template instances whose arguments are not literals)
+const char* ssdseg_intern(const char* name);
+
+#define SSDSEG_LAUNCH_NAMED(ctx, name, bytes, flops, kernel, grid, block, lds, ...)   \
+    do {                                                                              \
+        if ((ctx)->timing) ssdseg_timing_begin((ctx), (name), (bytes), (flops));      \
+        hipLaunchKernelGGL(kernel, grid, block, lds, (ctx)->stream, __VA_ARGS__);     \
+        if ((ctx)->timing) ssdseg_timing_end((ctx));                                  \
+    } while (0)
+
 #define SSDSEG_LAUNCH(ctx, bytes, flops, kernel, grid, block, lds, ...)               \
     do {                                                                              \
         if ((ctx)->timing) ssdseg_timing_begin((ctx), #kernel, (bytes), (flops));     \

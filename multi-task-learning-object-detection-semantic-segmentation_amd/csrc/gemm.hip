@@ -443,12 +443,15 @@ int launch_rowA(ssdseg_ctx* ctx, const RowAArgs& a) {
     // algorithmic: read the streamed operand and the weights once, write the output once
     const double cost_bytes = 4.0 * ((double)a.I * a.R + (double)a.I * a.J + (double)a.R * a.J);
     const double cost_flops = 2.0 * a.I * a.R * a.J;
+    char kbuf[64];
+    snprintf(kbuf, sizeof(kbuf), "gemm_rowA_kernel<%d, %d, %s>", wn, MODE, CONV ? "true" : "false");
+    const char* kname = ctx->timing ? ssdseg_intern(kbuf) : "";
     switch (wn) {
-        case 1: SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (gemm_rowA_kernel<1, MODE, CONV>), grid, dim3(256), lds, a); break;
-        case 2: SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (gemm_rowA_kernel<2, MODE, CONV>), grid, dim3(256), lds, a); break;
-        case 3: SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (gemm_rowA_kernel<3, MODE, CONV>), grid, dim3(256), lds, a); break;
-        case 4: SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (gemm_rowA_kernel<4, MODE, CONV>), grid, dim3(256), lds, a); break;
-        default: SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (gemm_rowA_kernel<5, MODE, CONV>), grid, dim3(256), lds, a); break;
+        case 1: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, MODE, CONV>), grid, dim3(256), lds, a); break;
+        case 2: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<2, MODE, CONV>), grid, dim3(256), lds, a); break;
+        case 3: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<3, MODE, CONV>), grid, dim3(256), lds, a); break;
+        case 4: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<4, MODE, CONV>), grid, dim3(256), lds, a); break;
+        default: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<5, MODE, CONV>), grid, dim3(256), lds, a); break;
     }
     SSDSEG_LAUNCH_CHECK();
     return 0;
@@ -463,12 +466,15 @@ int launch_wgrad_wn(ssdseg_ctx* ctx, const WGradArgs& a, int wn, dim3 grid) {
     const double cost_bytes = 4.0 * ((double)a.M * a.K + (double)a.M * a.N + (double)a.K * a.N);
     const double cost_flops = 2.0 * a.M * a.K * a.N;
     (void)share;
+    char kbuf[64];
+    snprintf(kbuf, sizeof(kbuf), "gemm_wgrad_kernel<%d, %d, %d>%s", WI, WR, wn, a.convH > 0 ? " [conv3x3 tap]" : "");
+    const char* kname = ctx->timing ? ssdseg_intern(kbuf) : "";
     switch (wn) {
-        case 1: SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (gemm_wgrad_kernel<WI, WR, 1>), grid, dim3(256), lds, a); break;
-        case 2: SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (gemm_wgrad_kernel<WI, WR, 2>), grid, dim3(256), lds, a); break;
-        case 3: SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (gemm_wgrad_kernel<WI, WR, 3>), grid, dim3(256), lds, a); break;
-        case 4: SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (gemm_wgrad_kernel<WI, WR, 4>), grid, dim3(256), lds, a); break;
-        default: SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (gemm_wgrad_kernel<WI, WR, 5>), grid, dim3(256), lds, a); break;
+        case 1: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_wgrad_kernel<WI, WR, 1>), grid, dim3(256), lds, a); break;
+        case 2: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_wgrad_kernel<WI, WR, 2>), grid, dim3(256), lds, a); break;
+        case 3: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_wgrad_kernel<WI, WR, 3>), grid, dim3(256), lds, a); break;
+        case 4: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_wgrad_kernel<WI, WR, 4>), grid, dim3(256), lds, a); break;
+        default: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_wgrad_kernel<WI, WR, 5>), grid, dim3(256), lds, a); break;
     }
     SSDSEG_LAUNCH_CHECK();
     return 0;

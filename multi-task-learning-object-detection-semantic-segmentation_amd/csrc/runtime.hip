@@ -57,6 +57,15 @@ struct ssdseg_timing {
     std::map<std::string, Stat> stats;
 };
 
+#include <mutex>
+#include <set>
+const char* ssdseg_intern(const char* name) {
+    static std::mutex mu;
+    static std::set<std::string> pool;
+    std::lock_guard<std::mutex> lock(mu);
+    return pool.insert(name).first->c_str();
+}
+
 static hipEvent_t timing_event(ssdseg_timing* t) {
     if (!t->pool.empty()) {
         hipEvent_t e = t->pool.back();

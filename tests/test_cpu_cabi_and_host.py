@@ -1,0 +1,96 @@
+"""C-ABI shape checks without a GPU: the library loads, exports every symbol include/ssdseg.h declares, and the
+host-side API mirrors the reference's error behaviour.  No compute call is made."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    from ssdseglib import _hip
+    if not os.path.exists(_hip.library_path()):
+        g.build()
+    return _hip.load_library()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    header = open(os.path.join(REPO, "include", "ssdseg.h")).read()
+    declared = set(re.findall(r"\b(ssdseg_[a-z0-9_]+)\s*\(", header)) - {"ssdseg_ctx", "ssdseg_view", "ssdseg_gview"}
+    assert len(declared) > 50
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, f"declared in ssdseg.h but not exported: {missing}"
+    from ssdseglib import _hip
+    unbound = sorted(declared - set(_hip.declared_symbols()))
+    assert not unbound, f"declared in ssdseg.h but without a ctypes signature: {unbound}"
+    assert lib.ssdseg_version() == 1
+
+
+def test_argument_errors_do_not_need_a_device(lib):
+    import ctypes as C
+    out = C.c_int()
+    assert lib.ssdseg_dwconv_parts(1, 8, 8, 6, 1, C.byref(out)) == -1000 - 4          # channels must be a multiple of 4
+    assert b"invalid argument 4" in lib.ssdseg_last_error()
+    assert lib.ssdseg_pwconv_parts(640, 96, C.byref(out)) == 0 and out.value == 5
+    assert lib.ssdseg_stem_conv_parts(2, 480, 640, 32, C.byref(out)) == 0 and out.value > 0
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    """the product path must not degrade to a CPU implementation"""
+    from ssdseglib import _hip
+    import ctypes as C
+    n = C.c_int()
+    rc = _hip.load_library().ssdseg_device_count(C.byref(n))
+    if rc == 0 and n.value > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_hip.SsdsegError):
+        _hip.Context(0)
+    import ssdseglib
+    with pytest.raises(_hip.SsdsegError):
+        ssdseglib.losses.localization_loss(np.zeros((1, 4, 4), np.float32), np.zeros((1, 4, 4), np.float32))
+
+
+def test_datacoder_constructor_like_reference(golden_dir):
+    import ssdseglib
+    d = np.load(f"{golden_dir}/anchors_nb03.npz")
+    corners = dict(xmin_boxes_default=d["xmin"], ymin_boxes_default=d["ymin"], xmax_boxes_default=d["xmax"], ymax_boxes_default=d["ymax"])
+    cents = dict(center_x_boxes_default=d["center_x"], center_y_boxes_default=d["center_y"], width_boxes_default=d["width"],
+                 height_boxes_default=d["height"])
+    enc = ssdseglib.datacoder.DataEncoderDecoder(4, (480, 640), iou_threshold=0.525, **corners)
+    assert np.array_equal(enc.center_x_boxes_default, d["center_x"]) and np.array_equal(enc.width_boxes_default, d["width"])
+    enc2 = ssdseglib.datacoder.DataEncoderDecoder(4, (480, 640), **cents)
+    assert np.allclose(enc2.xmin_boxes_default, d["xmin"], atol=1e-3)
+    with pytest.raises(ValueError):
+        ssdseglib.datacoder.DataEncoderDecoder(4, (480, 640), xmin_boxes_default=d["xmin"])          # reference datacoder.py:55-56
+    with pytest.raises(ValueError):
+        ssdseglib.datacoder.DataEncoderDecoder(4, (480, 640), center_x_boxes_default=d["center_x"])  # :74-75
+    with pytest.raises(ValueError):
+        ssdseglib.datacoder.DataEncoderDecoder(4, (480, 640), **corners, **cents)                    # quirk Q5 (:92-108)
+    # ground-truth decode helpers (host side) agree with the oracle
+    from oracle import np_ops as O
+    off = np.zeros((9600, 4), np.float32)
+    off[5] = [0.3, -0.2, 1.0, 2.0]
+    got = enc.decode_to_centroids(off)
+    assert np.allclose(got, O.decode_to_centroids_gt(off, d["centroids"], (0.1, 0.1, 0.2, 0.2)), atol=1e-4)
+    assert np.all(enc.decode_to_corners(off)[0] == 0) and np.any(enc.decode_to_corners(off)[5] != 0)
+    flipped = enc._flip_boxes(np.array([[1, 10, 20, 110, 220]], np.float32))
+    assert flipped.tolist() == [[1, 530, 20, 630, 220]]                                              # x -> W - x (quirk Q8)
+
+
+def test_metrics_and_loss_factories_shapes():
+    import ssdseglib
+    rng = np.random.default_rng(0)
+    y = np.eye(4, dtype=np.float32)[rng.integers(0, 4, (2, 6, 5))]
+    m = ssdseglib.metrics.jaccard_iou_segmentation_masks((0.05, 0.575, 0.135, 0.24))
+    assert np.allclose(m(y, y), 1.0)
+    acc = ssdseglib.metrics.categorical_accuracy((0.0, 1 / 3, 1 / 3, 1 / 3))
+    lab = np.eye(4, dtype=np.float32)[rng.integers(0, 4, (2, 50))]
+    assert acc(lab, lab).shape == (2,)
+    fn = ssdseglib.losses.cross_entropy((0.05, 0.575, 0.135, 0.24))
+    assert fn.loss_kind == "cross_entropy" and fn.classes_weights == (0.05, 0.575, 0.135, 0.24)
+    opt = ssdseglib.optimizers.Adam(learning_rate=1e-4)
+    assert (opt.learning_rate, opt.beta_1, opt.beta_2, opt.epsilon) == (1e-4, 0.9, 0.999, 1e-7)
