@@ -83,24 +83,13 @@ static inline void same_pad(int in, int k, int s, int d, int* out, int* before) 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// Keras ReLU(max_value) forward (App. B.4)
-__device__ __forceinline__ float act_apply(float z, int act) {
-    switch (act) {
-        case SSDSEG_ACT_RELU: return fmaxf(z, 0.f);
-        case SSDSEG_ACT_RELU6: return fminf(fmaxf(z, 0.f), 6.f);
-        case SSDSEG_ACT_ZERO: return 0.f;
-        default: return z;
-    }
-}
-// derivative mask of the activation at pre-activation z
-__device__ __forceinline__ float act_mask(float z, int act) {
-    switch (act) {
-        case SSDSEG_ACT_RELU: return z > 0.f ? 1.f : 0.f;
-        case SSDSEG_ACT_RELU6: return (z > 0.f && z < 6.f) ? 1.f : 0.f;
-        case SSDSEG_ACT_ZERO: return 0.f;
-        default: return 1.f;
-    }
-}
+// Keras ReLU(max_value) (App. B.4) as a clamp to [lo, hi] -- branch-free on the (wave-uniform) activation code:
+//   NONE [-inf, +inf] | RELU [0, +inf] | RELU6 [0, 6] | ZERO (max_value = 0.0, quirk Q1) [0, 0]
+__device__ __forceinline__ float act_lo(int act) { return act == SSDSEG_ACT_NONE ? -INFINITY : 0.f; }
+__device__ __forceinline__ float act_hi(int act) { return act == SSDSEG_ACT_RELU6 ? 6.f : (act == SSDSEG_ACT_ZERO ? 0.f : INFINITY); }
+__device__ __forceinline__ float act_apply(float z, int act) { return fminf(fmaxf(z, act_lo(act)), act_hi(act)); }
+// derivative of the activation at pre-activation z: 1 strictly inside (lo, hi), else 0
+__device__ __forceinline__ float act_mask(float z, int act) { return (z > act_lo(act) && z < act_hi(act)) ? 1.f : 0.f; }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -108,14 +97,23 @@ __device__ __forceinline__ float4 f4(float a) { return make_float4(a, a, a, a); 
 
 // a = act(scale*x + shift) on a 4-channel vector; has_affine == false -> act(x)
 __device__ __forceinline__ float4 view_apply4(float4 x, float4 s, float4 t, bool has_affine, int act) {
-    if (has_affine) {
-        x.x = fmaf(s.x, x.x, t.x); x.y = fmaf(s.y, x.y, t.y); x.z = fmaf(s.z, x.z, t.z); x.w = fmaf(s.w, x.w, t.w);
-    }
+    // identity affine instead of a branch (fma(1, x, 0) == x exactly)
+    if (!has_affine) { s = make_float4(1.f, 1.f, 1.f, 1.f); t = make_float4(0.f, 0.f, 0.f, 0.f); }
+    x.x = fmaf(s.x, x.x, t.x); x.y = fmaf(s.y, x.y, t.y); x.z = fmaf(s.z, x.z, t.z); x.w = fmaf(s.w, x.w, t.w);
     x.x = act_apply(x.x, act); x.y = act_apply(x.y, act); x.z = act_apply(x.z, act); x.w = act_apply(x.w, act);
     return x;
 }
 
-// dy = s*mask(s*y+t)*g + k1*y + k0 on a 4-channel vector
+// same with the affine always applied (callers substitute scale = 1, shift = 0 for identity views at set-up time, so the
+// per-element path has no branch at all)
+__device__ __forceinline__ float4 view_affine4(float4 x, float4 s, float4 t, float lo, float hi) {
+    x.x = fminf(fmaxf(fmaf(s.x, x.x, t.x), lo), hi); x.y = fminf(fmaxf(fmaf(s.y, x.y, t.y), lo), hi);
+    x.z = fminf(fmaxf(fmaf(s.z, x.z, t.z), lo), hi); x.w = fminf(fmaxf(fmaf(s.w, x.w, t.w), lo), hi);
+    return x;
+}
+
+// dy = s*mask(s*y+t)*g + k1*y + k0 on a 4-channel vector.  Identity gradient views are expressed as s = 1, t = k1 = k0 = 0,
+// act = NONE and y aliased to g (mask == 1 for finite values), so there is no per-element branch either.
 __device__ __forceinline__ float4 gview_apply4(float4 g, float4 y, float4 s, float4 t, float4 k1, float4 k0, int act) {
     float4 r;
     r.x = fmaf(s.x * act_mask(fmaf(s.x, y.x, t.x), act), g.x, fmaf(k1.x, y.x, k0.x));

@@ -39,18 +39,26 @@ struct GViewDev {
     int act;
 };
 
-struct ChanCoef {  // per-thread channel-vector constants
+struct ChanCoef {  // per-thread channel-vector constants (identity views: s = 1, t = k1 = k0 = 0)
     float4 s, t, k1, k0;
+    float lo, hi;  // activation clamp of an input view
     bool affine;
 };
 
 __device__ __forceinline__ float4 load_view(const ViewDev& v, const ChanCoef& cc, long long off) {
-    return view_apply4(ld4(v.x + off), cc.s, cc.t, cc.affine, v.act);
+    return view_affine4(ld4(v.x + off), cc.s, cc.t, cc.lo, cc.hi);
 }
 __device__ __forceinline__ float4 load_gview(const GViewDev& v, const ChanCoef& cc, long long off) {
-    float4 g = ld4(v.g + off);
-    if (!cc.affine) return g;
-    return gview_apply4(g, ld4(v.y + off), cc.s, cc.t, cc.k1, cc.k0, v.act);
+    return gview_apply4(ld4(v.g + off), ld4(v.y + off), cc.s, cc.t, cc.k1, cc.k0, v.act);
+}
+// predicated forms: the load is unconditional (address clamped to the thread's own channel vector of pixel 0) and the result
+// selected, so the compiler can issue a whole window of loads back to back instead of branch + wait per element
+__device__ __forceinline__ float4 sel4(bool ok, float4 v) { return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 load_view_if(const ViewDev& v, const ChanCoef& cc, long long off, bool ok, int c0) {
+    return sel4(ok, load_view(v, cc, ok ? off : (long long)c0));
+}
+__device__ __forceinline__ float4 load_gview_if(const GViewDev& v, const ChanCoef& cc, long long off, bool ok, int c0) {
+    return sel4(ok, load_gview(v, cc, ok ? off : (long long)c0));
 }
 __device__ __forceinline__ void fma4(float4& acc, float4 a, float4 b) {
     acc.x = fmaf(a.x, b.x, acc.x); acc.y = fmaf(a.y, b.y, acc.y); acc.z = fmaf(a.z, b.z, acc.z); acc.w = fmaf(a.w, b.w, acc.w);
@@ -81,7 +89,10 @@ __global__ void __launch_bounds__(512) dw_fwd_kernel(DwGeom gm, ViewDev in, cons
     float4 wk[9];
     ChanCoef cc;
     cc.affine = in.scale != nullptr;
-    cc.s = cc.t = cc.k1 = cc.k0 = f4(0.f);
+    cc.s = f4(1.f);
+    cc.t = cc.k1 = cc.k0 = f4(0.f);
+    cc.lo = act_lo(in.act);
+    cc.hi = act_hi(in.act);
     if (active) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) wk[t] = ld4(wgt + (long long)t * gm.c + c0);
@@ -106,13 +117,12 @@ __global__ void __launch_bounds__(512) dw_fwd_kernel(DwGeom gm, ViewDev in, cons
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh) {
                     const int hi = ho * S + kh - gm.pt;
-                    if (hi < 0 || hi >= gm.h) continue;
+                    const bool rowok = hi >= 0 && hi < gm.h;
                     float4 row[WC];
 #pragma unroll
                     for (int ci = 0; ci < WC; ++ci) {
                         const int wi = wi0 + ci;
-                        row[ci] = (wi >= 0 && wi < gm.w) ? load_view(in, cc, ((img + (long long)hi * gm.w + wi) * gm.c) + c0)
-                                                         : f4(0.f);
+                        row[ci] = load_view_if(in, cc, ((img + (long long)hi * gm.w + wi) * gm.c) + c0, rowok && wi >= 0 && wi < gm.w, c0);
                     }
 #pragma unroll
                     for (int j = 0; j < TW; ++j)
@@ -123,14 +133,14 @@ __global__ void __launch_bounds__(512) dw_fwd_kernel(DwGeom gm, ViewDev in, cons
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh) {
                     const int hi = ho + kh * gm.d - gm.pt;
-                    if (hi < 0 || hi >= gm.h) continue;
+                    const bool rowok = hi >= 0 && hi < gm.h;
 #pragma unroll
                     for (int kw = 0; kw < 3; ++kw) {
 #pragma unroll
                         for (int j = 0; j < TW; ++j) {
                             const int wi = wo0 + j + kw * gm.d - gm.pl;
-                            if (wi >= 0 && wi < gm.w && wo0 + j < gm.wo)
-                                fma4(out[j], load_view(in, cc, ((img + (long long)hi * gm.w + wi) * gm.c) + c0), wk[kh * 3 + kw]);
+                            fma4(out[j], load_view_if(in, cc, ((img + (long long)hi * gm.w + wi) * gm.c) + c0,
+                                                      rowok && wi >= 0 && wi < gm.w && wo0 + j < gm.wo, c0), wk[kh * 3 + kw]);
                         }
                     }
                 }
@@ -171,7 +181,11 @@ __global__ void __launch_bounds__(512) dw_bwd_kernel(DwGeom gm, ViewDev in, cons
     ChanCoef ci, co;  // input-side view coefficients, output-side gradient-view coefficients
     ci.affine = in.scale != nullptr;
     co.affine = dy.scale != nullptr;
-    ci.s = ci.t = ci.k1 = ci.k0 = co.s = co.t = co.k1 = co.k0 = f4(0.f);
+    ci.s = co.s = f4(1.f);
+    ci.t = ci.k1 = ci.k0 = co.t = co.k1 = co.k0 = f4(0.f);
+    ci.lo = act_lo(in.act); ci.hi = act_hi(in.act);
+    co.lo = co.hi = 0.f;
+    if (!co.affine) { dy.y = dy.g; dy.act = SSDSEG_ACT_NONE; }   // identity gradient view, branch-free form
     if (active) {
         if (ci.affine) { ci.s = ld4(in.scale + c0); ci.t = ld4(in.shift + c0); }
         if (co.affine) { co.s = ld4(dy.scale + c0); co.t = ld4(dy.shift + c0); co.k1 = ld4(dy.k1 + c0); co.k0 = ld4(dy.k0 + c0); }
@@ -200,9 +214,8 @@ __global__ void __launch_bounds__(512) dw_bwd_kernel(DwGeom gm, ViewDev in, cons
 #pragma unroll
                     for (int b = 0; b < TW + 2; ++b) {
                         const int ww = wo0 - 1 + b;
-                        dyw[a][b] = (hh >= 0 && hh < gm.ho && ww >= 0 && ww < gm.wo)
-                                        ? load_gview(dy, co, (oimg + (long long)hh * gm.wo + ww) * gm.c + c0)
-                                        : f4(0.f);
+                        dyw[a][b] = load_gview_if(dy, co, (oimg + (long long)hh * gm.wo + ww) * gm.c + c0,
+                                                  hh >= 0 && hh < gm.ho && ww >= 0 && ww < gm.wo, c0);
                     }
                 }
                 // ---- dx over the owned input patch
@@ -243,12 +256,12 @@ __global__ void __launch_bounds__(512) dw_bwd_kernel(DwGeom gm, ViewDev in, cons
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh) {
                     const int hi = ho * S + kh - PT;
-                    if (hi < 0 || hi >= gm.h) continue;
+                    const bool rowok = hi >= 0 && hi < gm.h;
                     float4 row[WC];
 #pragma unroll
                     for (int q = 0; q < WC; ++q) {
                         const int wi = wi0 + q;
-                        row[q] = (wi >= 0 && wi < gm.w) ? load_view(in, ci, (iimg + (long long)hi * gm.w + wi) * gm.c + c0) : f4(0.f);
+                        row[q] = load_view_if(in, ci, (iimg + (long long)hi * gm.w + wi) * gm.c + c0, rowok && wi >= 0 && wi < gm.w, c0);
                     }
 #pragma unroll
                     for (int kw = 0; kw < 3; ++kw)

@@ -70,6 +70,9 @@ __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
     float4 areg[4];
     float4 breg[WN];
 
+    const float alo = act_lo(p.act), ahi = act_hi(p.act);
+    const float* ya = affine ? p.a1 : p.a0;                       // identity gradient view: y aliases g, act NONE
+    const int gact = affine ? p.act : SSDSEG_ACT_NONE;
     int m0 = 0;
     int rn[4], rh[4], rw[4];   // CONV: (image, row, col) of this thread's 4 staged rows, fixed for a row tile
     auto load_tiles = [&](int kt) {
@@ -83,7 +86,7 @@ __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
             dh = (kh - 1) * p.convSign;
             dw = (tap - kh * 3 - 1) * p.convSign;
         }
-        float4 cs = f4(0.f), ct = f4(0.f), ck1 = f4(0.f), ck0 = f4(0.f);
+        float4 cs = f4(1.f), ct = f4(0.f), ck1 = f4(0.f), ck0 = f4(0.f);   // identity view unless per-channel coefficients exist
         if (affine && rin) {
             cs = ld4(p.cs + ch);
             ct = ld4(p.ct + ch);
@@ -100,15 +103,11 @@ __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
                 ok = ok && sh >= 0 && sh < p.convH && sw >= 0 && sw < p.convW;
                 off = (((long long)rn[i] * p.convH + sh) * p.convW + sw) * p.lda + ch;
             }
-            if (ok) {
-                if (MODE == 0) {
-                    v = view_apply4(ld4(p.a0 + off), cs, ct, affine, p.act);
-                } else {
-                    v = ld4(p.a0 + off);
-                    if (affine) v = gview_apply4(v, ld4(p.a1 + off), cs, ct, ck1, ck0, p.act);
-                }
-            }
-            areg[i] = v;
+            // unconditional loads from a clamped address + select: the 4 row loads (and their twins for y) issue back to back
+            if (!ok) off = 0;
+            if (MODE == 0) v = view_affine4(ld4(p.a0 + off), cs, ct, alo, ahi);
+            else v = gview_apply4(ld4(p.a0 + off), ld4(ya + off), cs, ct, ck1, ck0, gact);
+            areg[i] = ok ? v : f4(0.f);
         }
 #pragma unroll
         for (int q = 0; q < WN; ++q) {
@@ -117,13 +116,17 @@ __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
             if (MODE == 0) {
                 const int rr = idx / (8 * WN), j4 = idx % (8 * WN);
                 const int gr = kt * BK + rr, gj = j0 + j4 * 4;
-                if (gr < p.R && gj < p.J) v = ld4(p.b + (long long)gr * p.ldb + gj);
+                const bool bok = gr < p.R && gj < p.J;
+                v = ld4(p.b + (bok ? (long long)gr * p.ldb + gj : 0));
+                if (!bok) v = f4(0.f);
             } else {
                 const int jj = idx >> 3, r4 = idx & 7;
                 const int gr = kt * BK + r4 * 4, gj = j0 + jj;
                 // CONV: w[tap][j][c] with r = tap*convC + c  ->  j*convC + r + tap*convC*(J-1)
                 const long long tapoff = CONV ? (long long)(gr / p.convC) * p.convC * (p.J - 1) : 0;
-                if (gr < p.R && gj < p.J) v = ld4(p.b + (long long)gj * p.ldb + gr + tapoff);
+                const bool bok = gr < p.R && gj < p.J;
+                v = ld4(p.b + (bok ? (long long)gj * p.ldb + gr + tapoff : 0));
+                if (!bok) v = f4(0.f);
             }
             breg[q] = v;
         }
@@ -289,6 +292,9 @@ __global__ void __launch_bounds__(256) gemm_wgrad_kernel(WGradArgs p) {
     long long mend = mbeg + p.rows_per_split;
     if (mend > p.M) mend = p.M;
     const bool xaff = p.xs != nullptr, gaff = p.gs != nullptr;
+    const float xlo = act_lo(p.xact), xhi = act_hi(p.xact);
+    const float* yptr = gaff ? p.y : p.g;                        // identity gradient view: y aliases g, act NONE
+    const int yact = gaff ? p.gact : SSDSEG_ACT_NONE;
 
     constexpr int XV = BRT * BI / 4;   // float4 per X tile (== 256 * 2)
     constexpr int YV = BRT * BJ / 4;
@@ -316,10 +322,12 @@ __global__ void __launch_bounds__(256) gemm_wgrad_kernel(WGradArgs p) {
                     ok = hy >= 0 && hy < p.convH && wx >= 0 && wx < p.convW;
                     src = (img * p.convH + hy) * p.convW + wx;
                 }
-                if (ok) {
-                    float4 s = f4(0.f), sh = f4(0.f);
-                    if (xaff) { s = ld4(p.xs + k); sh = ld4(p.xt + k); }
-                    v = view_apply4(ld4(p.x + src * p.ldx + k), s, sh, xaff, p.xact);
+                {
+                    const int kk = ok ? k : 0;
+                    float4 s = f4(1.f), sh = f4(0.f);
+                    if (xaff) { s = ld4(p.xs + kk); sh = ld4(p.xt + kk); }
+                    v = view_affine4(ld4(p.x + (ok ? src * p.ldx + k : 0)), s, sh, xlo, xhi);
+                    if (!ok) v = f4(0.f);
                 }
             }
             xreg[q] = v;
@@ -332,9 +340,14 @@ __global__ void __launch_bounds__(256) gemm_wgrad_kernel(WGradArgs p) {
                 const int rr = idx / (BJ / 4), c4 = idx % (BJ / 4);
                 const long long m = mrow + rr;
                 const int n = j0 + c4 * 4;
-                if (m < mend && n < p.N) {
-                    v = ld4(p.g + m * p.ldy + n);
-                    if (gaff) v = gview_apply4(v, ld4(p.y + m * p.ldy + n), ld4(p.gs + n), ld4(p.gt + n), ld4(p.gk1 + n), ld4(p.gk0 + n), p.gact);
+                {
+                    const bool ok = m < mend && n < p.N;
+                    const long long o = ok ? m * p.ldy + n : 0;
+                    const int nn = ok ? n : 0;
+                    float4 gs = f4(1.f), gt = f4(0.f), gk1 = f4(0.f), gk0 = f4(0.f);
+                    if (gaff) { gs = ld4(p.gs + nn); gt = ld4(p.gt + nn); gk1 = ld4(p.gk1 + nn); gk0 = ld4(p.gk0 + nn); }
+                    v = gview_apply4(ld4(p.g + o), ld4(yptr + o), gs, gt, gk1, gk0, yact);
+                    if (!ok) v = f4(0.f);
                 }
             }
             yreg[q] = v;

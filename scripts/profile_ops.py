@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Per-op (per-layer) kernel timing of one engine step via the C library's HIP-event registry.
+usage: python scripts/profile_ops.py [backbone|full] [batch]  -> table sorted by time (fwd and bwd separately)"""
+import os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "multi-task-learning-object-detection-semantic-segmentation_amd"))
+import numpy as np
+import bench
+from ssdseglib import _hip as H
+
+workload = sys.argv[1] if len(sys.argv) > 1 else "backbone"
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+ctx = H.Context(0)
+step = (bench.BackboneStep if workload == "backbone" else bench.FullStep)(ctx, batch, 0, None)
+for _ in range(2):
+    step()
+ctx.sync()
+eng = step.eng
+rows = []
+ctx.timing(True)
+REP = 3
+for direction in ("fwd", "bwd"):
+    ops = eng.ops if direction == "fwd" else list(reversed(eng.ops))
+    if direction == "bwd":
+        for s in eng.stores: s.gwritten = False
+        if workload == "backbone":
+            for i, g in enumerate(step.seeds): eng.seed_output_grad(i, g)
+            eng.mark_output_grads_written()
+    for op in ops:
+        ctx.timing_reset()
+        snap = [s.gwritten for s in eng.stores]
+        for r in range(REP):
+            for s, w in zip(eng.stores, snap): s.gwritten = w      # same accumulate flags on every repeat
+            getattr(op, direction)()
+        rep = ctx.timing_report()
+        for k, v in rep.items():
+            if v["ms"] <= 0: continue
+            ms = v["ms"] / REP
+            rows.append((ms, direction, op.name or type(op).__name__, k, v["bytes"] / v["count"], v["flops"] / v["count"], v["count"] // REP))
+ctx.timing(False)
+rows.sort(reverse=True)
+total = sum(r[0] for r in rows)
+print(f"total kernel ms/step {total:.3f}")
+for ms, d, name, k, b, f, cnt in rows[:int(os.environ.get('TOP', '60'))]:
+    print(f"{ms*1e3:9.1f} us {d} {name:44s} {k:44s} x{cnt} {b/ms/1e6:8.0f} GB/s {f/ms/1e9:7.1f} TF")
