@@ -101,6 +101,8 @@ int ssdseg_event_elapsed_ms(ssdseg_ctx* ctx, void* ev_start, void* ev_stop, floa
  * report: one "kernel\tcount\ttotal_ms\tbytes\tflops\n" line per kernel into buf_host. */
 int ssdseg_timing_enable(ssdseg_ctx* ctx, int enable);
 int ssdseg_timing_reset(ssdseg_ctx* ctx);
+/* bracket only launches of one kernel symbol (low overhead inside a timed region); NULL or "" = every kernel */
+int ssdseg_timing_filter(ssdseg_ctx* ctx, const char* kernel);
 int ssdseg_timing_report(ssdseg_ctx* ctx, char* buf_host, size_t buf_len);
 /* hipGraph capture of a sequence of launches on the ctx stream (launch-bound inner loops) */
 int ssdseg_graph_begin(ssdseg_ctx* ctx);

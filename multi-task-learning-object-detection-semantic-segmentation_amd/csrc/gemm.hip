@@ -44,14 +44,22 @@ struct RowAArgs {
     // dense 3x3 stride-1 SAME convolution as implicit GEMM (CONV kernels): the reduction axis is (tap, channel) with
     // convC channels per tap, row m = (n, h, w) reads the streamed operand at (h + sign*(kh-1), w + sign*(kw-1))
     int convH, convW, convC, convSign;
+    // stem (LD == 2): 3x3 stride-2 SAME conv on a 3-channel image as implicit GEMM with R = 27 = (kh, kw, ci); row m =
+    // (n, ho, wo) over convH x convW OUTPUT pixels reads image (2*ho + kh - stemPt, 2*wo + kw - stemPl, ci) of a
+    // stemH x stemW image, rescaled on load (x*stemScale + stemOffset; padding stays 0).  bias: optional, added in the epilogue.
+    int stemH, stemW, stemPt, stemPl;
+    float stemScale, stemOffset;
+    const float* bias;
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-template <int WN, int MODE, bool CONV>
+// LD: how the streamed operand is addressed -- 0 plain row-major matrix, 1 dense 3x3 stride-1 gather, 2 stem gather
+template <int WN, int MODE, int LD>
 __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
+    constexpr bool CONV = LD == 1, STEM = LD == 2;
     constexpr int BN = 32 * WN;
     constexpr int BS = BN + 1;
     extern __shared__ float smem[];
@@ -102,6 +110,21 @@ __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
                 const int sh = rh[i] + dh, sw = rw[i] + dw;
                 ok = ok && sh >= 0 && sh < p.convH && sw >= 0 && sw < p.convW;
                 off = (((long long)rn[i] * p.convH + sh) * p.convW + sw) * p.lda + ch;
+            }
+            if (STEM) {
+                // four scalar gathers: r .. r+3 are (kh, kw, ci) triples of a 3-channel pixel row, not 16-byte aligned
+                float e[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int rq = r + q, tap = rq / 3, ci = rq - tap * 3, kh = tap / 3, kw = tap - kh * 3;
+                    const int hi = 2 * rh[i] + kh - p.stemPt, wi = 2 * rw[i] + kw - p.stemPl;
+                    const bool okq = rq < p.R && m < p.I && hi >= 0 && hi < p.stemH && wi >= 0 && wi < p.stemW;
+                    const long long o = okq ? (((long long)rn[i] * p.stemH + hi) * p.stemW + wi) * 3 + ci : 0;
+                    const float x = p.a0[o];
+                    e[q] = okq ? fmaf(x, p.stemScale, p.stemOffset) : 0.f;
+                }
+                areg[i] = make_float4(e[0], e[1], e[2], e[3]);
+                continue;
             }
             // unconditional loads from a clamped address + select: the 4 row loads (and their twins for y) issue back to back
             if (!ok) off = 0;
@@ -156,7 +179,7 @@ __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
     // a block walks row tiles blockIdx.y, blockIdx.y + gridDim.y, ... so the number of BN partial rows stays small
     for (int mt = blockIdx.y; mt < mtiles; mt += gridDim.y) {
     m0 = mt * BM;
-    if (CONV) {
+    if (CONV || STEM) {
         const int hw = p.convH * p.convW;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -206,6 +229,7 @@ __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
                 const int m = m0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
                 if (m < p.I) {
                     float v = acc[nt][e];
+                    if (STEM && p.bias) v += p.bias[j];
                     if (MODE == 1) {
                         if (p.residual) v += p.residual[(long long)m * p.ldr + j];
                         if (p.accumulate) v += p.out[(long long)m * p.ldo + j];
@@ -271,6 +295,9 @@ struct WGradArgs {
     int rows_per_split;
     // one tap of a dense 3x3 conv: row m = (n, h, w) reads x at (h + dh, w + dw); convH == 0 -> plain GEMM
     int convH, convW, dh, dw;
+    // stem: x is the 3-channel image, row m = (n, ho, wo) over convH x convW output pixels, k = (kh, kw, ci) (see RowAArgs)
+    int stem, stemH, stemW, stemPt, stemPl;
+    float stemScale, stemOffset;
 };
 
 constexpr int RW = 16;  // reduction rows per wave per step
@@ -314,6 +341,23 @@ __global__ void __launch_bounds__(256) gemm_wgrad_kernel(WGradArgs p) {
                 const int k = i0 + c4 * 4;
                 bool ok = m < mend && k < p.K;
                 long long src = m;
+                if (p.stem) {
+                    const long long hw = (long long)p.convH * p.convW;
+                    const long long img = m / hw;
+                    const int rem = (int)(m - img * hw);
+                    const int ho = rem / p.convW, wo = rem - ho * p.convW;
+                    float e[4];
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const int rq = k + qq, tap = rq / 3, ci = rq - tap * 3, kh = tap / 3, kw = tap - kh * 3;
+                        const int hi = 2 * ho + kh - p.stemPt, wi = 2 * wo + kw - p.stemPl;
+                        const bool okq = m < mend && rq < p.K && hi >= 0 && hi < p.stemH && wi >= 0 && wi < p.stemW;
+                        const float xv = p.x[okq ? ((img * p.stemH + hi) * p.stemW + wi) * 3 + ci : 0];
+                        e[qq] = okq ? fmaf(xv, p.stemScale, p.stemOffset) : 0.f;
+                    }
+                    xreg[q] = make_float4(e[0], e[1], e[2], e[3]);
+                    continue;
+                }
                 if (p.convH > 0 && ok) {
                     const long long hw = (long long)p.convH * p.convW;
                     const long long img = m / hw;
@@ -424,31 +468,43 @@ __global__ void __launch_bounds__(256) gemm_wgrad_kernel(WGradArgs p) {
     }
 }
 
-// pick the column-tile width (in 32-col MFMA tiles) that wastes the fewest padded columns; ties -> wider
-int pick_wn(int n) {
+// Column-tile width in 32-col MFMA tiles.  `row_blocks` = how many blocks the launch has per column tile.
+// Among the widths that still give the chip >= 2 blocks per CU, take the one wasting the fewest padded columns (ties ->
+// wider: more reuse of the streamed operand per block); if no width reaches that, take the one with the most blocks
+// (the 15x20 / 8x10 layers have only 75 / 20 row tiles: a 160-wide tile would leave 180 of 256 CUs idle).
+int pick_wn(int n, long long row_blocks) {
     int best = 1;
-    long long best_pad = -1;
+    long long best_pad = -1, best_blocks = -1;
+    bool best_full = false;
     for (int wn = 1; wn <= 5; ++wn) {
-        long long tiles = (n + 32 * wn - 1) / (32 * wn);
-        long long pad = tiles * 32 * wn;
-        if (best_pad < 0 || pad <= best_pad) { best_pad = pad; best = wn; }
+        const long long tiles = (n + 32 * wn - 1) / (32 * wn);
+        const long long pad = tiles * 32 * wn, blocks = tiles * row_blocks;
+        const bool full = blocks >= 512;
+        bool take;
+        if (best_pad < 0) take = true;
+        else if (full != best_full) take = full;
+        else if (full) take = pad <= best_pad;
+        else take = blocks > best_blocks || (blocks == best_blocks && pad <= best_pad);
+        if (take) { best = wn; best_pad = pad; best_blocks = blocks; best_full = full; }
     }
     return best;
 }
 
+int rowA_wn(int rows, int cols) { return pick_wn(cols, cdiv(rows, BM)); }
+
 // row-tile slots per column tile: enough blocks to fill the chip (~8 per CU), few enough that the BN partial
 // table stays short
 int rowA_grid_y(int rows, int cols) {
-    const int wn = pick_wn(cols);
+    const int wn = rowA_wn(rows, cols);
     const int ntiles = cdiv(cols, 32 * wn), mtiles = cdiv(rows, BM);
     int gy = 2048 / ntiles;
     if (gy < 1) gy = 1;
     return mtiles < gy ? mtiles : gy;
 }
 
-template <int MODE, bool CONV>
+template <int MODE, int LD>
 int launch_rowA(ssdseg_ctx* ctx, const RowAArgs& a) {
-    const int wn = pick_wn(a.J);
+    const int wn = rowA_wn(a.I, a.J);
     dim3 grid(cdiv(a.J, 32 * wn), rowA_grid_y(a.I, a.J), 1);
     size_t lds = (size_t)(BM * AS + BK * (32 * wn + 1)) * sizeof(float);
     size_t red = (size_t)(4 * 2 * 32 * wn) * sizeof(float);
@@ -457,14 +513,14 @@ int launch_rowA(ssdseg_ctx* ctx, const RowAArgs& a) {
     const double cost_bytes = 4.0 * ((double)a.I * a.R + (double)a.I * a.J + (double)a.R * a.J);
     const double cost_flops = 2.0 * a.I * a.R * a.J;
     char kbuf[64];
-    snprintf(kbuf, sizeof(kbuf), "gemm_rowA_kernel<%d, %d, %s>", wn, MODE, CONV ? "true" : "false");
+    snprintf(kbuf, sizeof(kbuf), "gemm_rowA_kernel<%d, %d, %d>", wn, MODE, LD);
     const char* kname = ctx->timing ? ssdseg_intern(kbuf) : "";
     switch (wn) {
-        case 1: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, MODE, CONV>), grid, dim3(256), lds, a); break;
-        case 2: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<2, MODE, CONV>), grid, dim3(256), lds, a); break;
-        case 3: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<3, MODE, CONV>), grid, dim3(256), lds, a); break;
-        case 4: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<4, MODE, CONV>), grid, dim3(256), lds, a); break;
-        default: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<5, MODE, CONV>), grid, dim3(256), lds, a); break;
+        case 1: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, MODE, LD>), grid, dim3(256), lds, a); break;
+        case 2: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<2, MODE, LD>), grid, dim3(256), lds, a); break;
+        case 3: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<3, MODE, LD>), grid, dim3(256), lds, a); break;
+        case 4: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<4, MODE, LD>), grid, dim3(256), lds, a); break;
+        default: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<5, MODE, LD>), grid, dim3(256), lds, a); break;
     }
     SSDSEG_LAUNCH_CHECK();
     return 0;
@@ -496,14 +552,19 @@ int launch_wgrad_wn(ssdseg_ctx* ctx, const WGradArgs& a, int wn, dim3 grid) {
 // picks the tile shape / split count for dw[k][n] = sum_m x[m][k]*dy[m][n], launches, reduces the split partials
 int wgrad_run(ssdseg_ctx* ctx, WGradArgs a, float* dw) {
     const int m = a.M, k = a.K, n = a.N;
-    const int wn = pick_wn(n);
     const int wi = k <= 32 ? 1 : (k <= 64 ? 2 : 4);
     const int wr = 4 / wi;
     const int brt = RW * wr;
-    const int itiles = cdiv(k, 32 * wi), jtiles = cdiv(n, 32 * wn);
+    const int itiles = cdiv(k, 32 * wi);
     long long steps = ((long long)m + brt - 1) / brt;
+    // split the reduction rows so that (a) the chip is full, (b) every block still does >= 4 steps and (c) the partial
+    // slabs (splits*k*n floats, written then re-read) stay below half of the operand traffic m*(k+n)
+    long long max_splits = (steps + 3) / 4;
+    const long long traffic_cap = (long long)((double)m * (k + n) / (2.0 * k * n));
+    if (max_splits > traffic_cap) max_splits = traffic_cap < 1 ? 1 : traffic_cap;
+    const int wn = pick_wn(n, (long long)itiles * max_splits);
+    const int jtiles = cdiv(n, 32 * wn);
     long long want = (4LL * ctx->num_cus + (long long)itiles * jtiles - 1) / ((long long)itiles * jtiles);
-    long long max_splits = (steps + 3) / 4;  // at least 4 steps per block
     long long splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
     if (splits > 65535) splits = 65535;
     long long steps_per_split = (steps + splits - 1) / splits;
@@ -557,7 +618,7 @@ int ssdseg_pwconv_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const flo
     a.out = y; a.ldo = ldy;
     a.stats = stats;
     a.I = m; a.R = k; a.J = n;
-    return launch_rowA<0, false>(ctx, a);
+    return launch_rowA<0, 0>(ctx, a);
 }
 
 int ssdseg_pwconv_bwd_data(ssdseg_ctx* ctx, const ssdseg_gview* dy, int ldy, const float* w, float* dx, int ldx, int m,
@@ -580,7 +641,7 @@ int ssdseg_pwconv_bwd_data(ssdseg_ctx* ctx, const ssdseg_gview* dy, int ldy, con
     a.out = dx; a.ldo = ldx;
     a.residual = residual; a.ldr = ldr; a.accumulate = accumulate;
     a.I = m; a.R = n; a.J = k;
-    return launch_rowA<1, false>(ctx, a);
+    return launch_rowA<1, 0>(ctx, a);
 }
 
 int ssdseg_pwconv_bwd_weight(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssdseg_gview* dy, int ldy, float* dw,
@@ -601,6 +662,85 @@ int ssdseg_pwconv_bwd_weight(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, co
     a.ldy = ldy;
     a.M = m; a.K = k; a.N = n;
     return wgrad_run(ctx, a, dw);
+}
+
+// ------------------------------------------------------------------------------------------------ stem (K1 + K2)
+// Rescaling + Conv2D 3x3 stride 2 SAME on the 3-channel image (reference models.py:187,196 -> :65; ShuffleNetV2 :622,628)
+// as implicit GEMM [n*ho*wo, 27] x [27, cout] through the same MFMA kernels: the im2col gather happens in the LDS
+// loader, the output leaves the accumulators as full 128-byte row segments, BN statistics come from the epilogue.
+static void stem_geometry(int h, int wdt, int* ho, int* wo, int* pt, int* pl) {
+    same_pad(h, 3, 2, 1, ho, pt);
+    same_pad(wdt, 3, 2, 1, wo, pl);
+}
+
+int ssdseg_stem_conv_parts(int n, int h, int w, int cout, int* nparts_host) {
+    SSDSEG_ARG(n > 0 && h > 0 && w > 0, 1);
+    SSDSEG_ARG(cout > 0 && cout % 4 == 0, 4);
+    SSDSEG_ARG(nparts_host != nullptr, 5);
+    int ho, wo, pt, pl;
+    stem_geometry(h, w, &ho, &wo, &pt, &pl);
+    *nparts_host = rowA_grid_y(n * ho * wo, cout);
+    return 0;
+}
+
+int ssdseg_stem_conv_fwd(ssdseg_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int n, int h, int wdt,
+                         int cin, int cout, float in_scale, float in_offset, float* stats) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(x != nullptr, 2);
+    SSDSEG_ARG(w != nullptr, 3);
+    SSDSEG_ARG(bias == nullptr || stats == nullptr, 4);   // a biased conv is never followed by BatchNormalization here
+    SSDSEG_ARG(y != nullptr, 5);
+    SSDSEG_ARG(n > 0 && h > 0 && wdt > 0, 6);
+    SSDSEG_ARG(cin == 3, 9);
+    SSDSEG_ARG(cout > 0 && cout % 4 == 0, 10);
+    RowAArgs a{};
+    a.a0 = x; a.act = SSDSEG_ACT_NONE;
+    a.b = w; a.ldb = cout;
+    a.out = y; a.ldo = cout;
+    a.stats = stats;
+    a.bias = bias;
+    stem_geometry(h, wdt, &a.convH, &a.convW, &a.stemPt, &a.stemPl);
+    a.stemH = h; a.stemW = wdt; a.stemScale = in_scale; a.stemOffset = in_offset;
+    a.I = n * a.convH * a.convW; a.R = 27; a.J = cout;
+    return launch_rowA<0, 2>(ctx, a);
+}
+
+int ssdseg_stem_conv_bwd_weight(ssdseg_ctx* ctx, const float* x, const ssdseg_gview* dy, float* dw, float* dbias, int n, int h,
+                                int wdt, int cin, int cout, float in_scale, float in_offset) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(x != nullptr, 2);
+    SSDSEG_ARG(dy != nullptr && dy->g != nullptr, 3);
+    SSDSEG_ARG(dy->scale == nullptr || (dy->y && dy->shift && dy->k1 && dy->k0), 3);
+    SSDSEG_ARG(dbias == nullptr || dy->scale == nullptr, 5);   // the bias gradient is the plain column sum of g
+    SSDSEG_ARG(dw != nullptr, 4);
+    SSDSEG_ARG(n > 0 && h > 0 && wdt > 0, 6);
+    SSDSEG_ARG(cin == 3, 9);
+    SSDSEG_ARG(cout > 0 && cout % 4 == 0, 10);
+    WGradArgs a{};
+    a.x = x; a.xact = SSDSEG_ACT_NONE;
+    a.g = dy->g; a.y = dy->y; a.gs = dy->scale; a.gt = dy->shift; a.gk1 = dy->k1; a.gk0 = dy->k0; a.gact = dy->act;
+    a.ldy = cout;
+    a.stem = 1;
+    stem_geometry(h, wdt, &a.convH, &a.convW, &a.stemPt, &a.stemPl);
+    a.stemH = h; a.stemW = wdt; a.stemScale = in_scale; a.stemOffset = in_offset;
+    a.M = n * a.convH * a.convW; a.K = 27; a.N = cout;
+    int rc = wgrad_run(ctx, a, dw);
+    if (rc || !dbias) return rc;
+    // dbias[c] = sum_m g[m][c]: per-block channel sums, then the fixed-order fold
+    int nparts = 0;
+    rc = ssdseg_channel_stats_parts(a.M, cout, &nparts);
+    if (rc) return rc;
+    void* ws;
+    rc = ssdseg_workspace(ctx, ((size_t)nparts * 2 * cout + 2 * (size_t)cout) * sizeof(float), &ws);
+    if (rc) return rc;
+    float* part = (float*)ws;
+    float* both = part + (size_t)nparts * 2 * cout;
+    rc = ssdseg_channel_stats(ctx, dy->g, cout, a.M, cout, part);
+    if (rc) return rc;
+    rc = ssdseg_colsum(ctx, part, nparts, 2LL * cout, both);
+    if (rc) return rc;
+    SSDSEG_HIP(hipMemcpyAsync(dbias, both, (size_t)cout * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------ dense 3x3 (K6)
@@ -629,7 +769,7 @@ int ssdseg_conv3x3_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const fl
     a.stats = stats;
     a.I = n * h * wdt; a.R = 9 * cin; a.J = cout;
     a.convH = h; a.convW = wdt; a.convC = cin; a.convSign = 1;
-    return launch_rowA<0, true>(ctx, a);
+    return launch_rowA<0, 1>(ctx, a);
 }
 
 int ssdseg_conv3x3_bwd_data(ssdseg_ctx* ctx, const ssdseg_gview* dy, const float* w, float* dx, int ldx, int n, int h, int wdt,
@@ -651,7 +791,7 @@ int ssdseg_conv3x3_bwd_data(ssdseg_ctx* ctx, const ssdseg_gview* dy, const float
     a.accumulate = accumulate;
     a.I = n * h * wdt; a.R = 9 * cout; a.J = cin;
     a.convH = h; a.convW = wdt; a.convC = cout; a.convSign = -1;   // dx(h,w) gathers dy(h-(kh-1), w-(kw-1))
-    return launch_rowA<1, true>(ctx, a);
+    return launch_rowA<1, 1>(ctx, a);
 }
 
 int ssdseg_conv3x3_bwd_weight(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssdseg_gview* dy, float* dw, int n, int h,

@@ -55,6 +55,8 @@ struct ssdseg_timing {
     std::vector<Pending> pending;
     std::vector<hipEvent_t> pool;
     std::map<std::string, Stat> stats;
+    std::string filter;     // non-empty: only launches of this kernel symbol are bracketed (low-overhead mode)
+    bool open = false;      // the last begin() recorded a start event that still needs its stop
 };
 
 #include <mutex>
@@ -99,6 +101,9 @@ static void timing_fold(ssdseg_ctx* ctx) {
 void ssdseg_timing_begin(ssdseg_ctx* ctx, const char* kernel, double bytes, double flops) {
     ssdseg_timing* t = ctx->timing;
     if (!t || ctx->capturing) return;
+    t->open = false;
+    if (!t->filter.empty() && t->filter != kernel) return;
+    t->open = true;
     if (t->pending.size() >= 8192) timing_fold(ctx);
     ssdseg_timing::Pending p{kernel, timing_event(t), timing_event(t), bytes, flops};
     (void)hipEventRecord(p.start, ctx->stream);
@@ -107,7 +112,8 @@ void ssdseg_timing_begin(ssdseg_ctx* ctx, const char* kernel, double bytes, doub
 
 void ssdseg_timing_end(ssdseg_ctx* ctx) {
     ssdseg_timing* t = ctx->timing;
-    if (!t || ctx->capturing || t->pending.empty()) return;
+    if (!t || ctx->capturing || !t->open || t->pending.empty()) return;
+    t->open = false;
     (void)hipEventRecord(t->pending.back().stop, ctx->stream);
 }
 
@@ -122,6 +128,15 @@ int ssdseg_timing_enable(ssdseg_ctx* ctx, int enable) {
         delete ctx->timing;
         ctx->timing = nullptr;
     }
+    return 0;
+}
+
+// restrict the event bracketing to one kernel symbol (NULL or "" = every kernel)
+int ssdseg_timing_filter(ssdseg_ctx* ctx, const char* kernel) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(ctx->timing != nullptr, 1);
+    timing_fold(ctx);
+    ctx->timing->filter = kernel ? kernel : "";
     return 0;
 }
 

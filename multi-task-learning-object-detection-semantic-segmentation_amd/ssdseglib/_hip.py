@@ -56,6 +56,7 @@ _SIGNATURES = {
     "ssdseg_event_elapsed_ms": [_vp, _vp, _vp, C.POINTER(_f)],
     "ssdseg_timing_enable": [_vp, _i],
     "ssdseg_timing_reset": [_vp],
+    "ssdseg_timing_filter": [_vp, C.c_char_p],
     "ssdseg_timing_report": [_vp, C.c_char_p, _sz],
     "ssdseg_graph_begin": [_vp],
     "ssdseg_graph_end": [_vp, C.POINTER(_vp)],
@@ -298,6 +299,9 @@ class Context:
     # ---- per-kernel HIP-event timing (bench.py roofline leg)
     def timing(self, enable: bool):
         _check(self.lib.ssdseg_timing_enable(self.handle, 1 if enable else 0), "ssdseg_timing_enable")
+
+    def timing_filter(self, kernel: Optional[str]):
+        _check(self.lib.ssdseg_timing_filter(self.handle, kernel.encode() if kernel else None), "ssdseg_timing_filter")
 
     def timing_reset(self):
         _check(self.lib.ssdseg_timing_reset(self.handle), "ssdseg_timing_reset")

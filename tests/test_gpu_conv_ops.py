@@ -239,15 +239,21 @@ def test_stem_conv(ctx, rng, n, h, w, cout, bias):
     y = ctx.empty(y_ref.shape)
     nparts = ctx.parts("ssdseg_stem_conv_parts", n, h, w, cout)
     stats = ctx.empty((nparts, 2, cout))
-    ctx.call("ssdseg_stem_conv_fwd", dx_, dw_, db_, y, n, h, w, 3, cout, 1.0 / 127.5, -1.0, stats)
+    # BN statistics are only requested for the bias-free stem (a biased conv is never followed by BatchNormalization)
+    ctx.call("ssdseg_stem_conv_fwd", dx_, dw_, db_, y, n, h, w, 3, cout, 1.0 / 127.5, -1.0, None if bias else stats)
     assert rel_err(y.download(), y_ref) < 2e-5
-    st = stats.download().astype(np.float64).sum(axis=0)
-    assert rel_err(st[1], (y_ref.astype(np.float64) ** 2).sum(axis=(0, 1, 2))) < 1e-4
+    if not bias:
+        st = stats.download().astype(np.float64).sum(axis=0)
+        assert rel_err(st[1], (y_ref.astype(np.float64) ** 2).sum(axis=(0, 1, 2))) < 1e-4
     g, yraw, gs, gt, k1, k0, dy = make_gview_inputs(rng, y_ref.shape, O.ACT_RELU6)
     bufs = [ctx.array(v) for v in (g, yraw, gs, gt, k1, k0)]
     dwg = ctx.empty(wgt.shape)
+    ctx.call("ssdseg_stem_conv_bwd_weight", dx_, H.gview(*bufs, act=O.ACT_RELU6), dwg, None, n, h, w, 3, cout, 1.0 / 127.5, -1.0)
+    _, dw_ref, _ = O.conv2d_bwd(xr.astype(np.float64), wgt.astype(np.float64), dy.astype(np.float64), 2, 1)
+    assert rel_err(dwg.download(), dw_ref) < 1e-4
+    # biased stem (ShuffleNetV2, reference models.py:628): no BatchNormalization follows, so the gradient view is the identity
     dbg = ctx.empty(cout)
-    ctx.call("ssdseg_stem_conv_bwd_weight", dx_, H.gview(*bufs, act=O.ACT_RELU6), dwg, dbg, n, h, w, 3, cout, 1.0 / 127.5, -1.0)
-    _, dw_ref, db_ref = O.conv2d_bwd(xr.astype(np.float64), wgt.astype(np.float64), dy.astype(np.float64), 2, 1)
+    ctx.call("ssdseg_stem_conv_bwd_weight", dx_, H.gview(bufs[0]), dwg, dbg, n, h, w, 3, cout, 1.0 / 127.5, -1.0)
+    _, dw_ref, db_ref = O.conv2d_bwd(xr.astype(np.float64), wgt.astype(np.float64), g.astype(np.float64), 2, 1)
     assert rel_err(dwg.download(), dw_ref) < 1e-4
     assert rel_err(dbg.download(), db_ref) < 1e-4
