@@ -128,7 +128,7 @@ int ssdseg_stem_conv_bwd_weight(ssdseg_ctx* ctx, const float* x, const ssdseg_gv
  * DepthwiseConv2D / depthwise half of SeparableConv2D, SAME padding, depth multiplier 1
  * (models.py:88,236,242,524,533,542,577,586; blocks.py:33,38,43,122,152).
  * TF SAME: out = ceil(in/s), pad_total = max((out-1)*s + (k-1)*d + 1 - in, 0), before = pad_total/2. */
-int ssdseg_dwconv_parts(int n, int h, int w, int c, int stride, int* nparts_host);
+int ssdseg_dwconv_parts(int n, int h, int w, int c, int stride, int dilation, int* nparts_host);
 int ssdseg_dwconv_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, float* y, int n, int h, int wdt,
                       int c, int stride, int dilation, float* stats);
 /* dx (= dL/d(act output of the producer), same shape as the input) and dw [3][3][c] in one pass.

@@ -338,19 +338,23 @@ bool dw_geometry(int n, int h, int w, int c, int stride, int dilation, DwGeom* g
 
 }  // namespace
 
+#include "dwconv_lds.h"
+
 int ssdseg_colsum(ssdseg_ctx* ctx, const float* part, int nparts, long long len, float* out);  // bn.hip
 
 extern "C" {
 
-int ssdseg_dwconv_parts(int n, int h, int w, int c, int stride, int* nparts_host) {
+int ssdseg_dwconv_parts(int n, int h, int w, int c, int stride, int dilation, int* nparts_host) {
     SSDSEG_ARG(n > 0 && h > 0 && w > 0, 1);
     SSDSEG_ARG(c > 0 && c % 4 == 0, 4);
     SSDSEG_ARG(stride == 1 || stride == 2, 5);
-    SSDSEG_ARG(nparts_host != nullptr, 6);
+    SSDSEG_ARG(dilation >= 1 && (dilation == 1 || stride == 1), 6);
+    SSDSEG_ARG(nparts_host != nullptr, 7);
     DwGeom g;
     DwLaunch l;
-    dw_geometry(n, h, w, c, stride, 1, &g, &l);  // the strip count does not depend on the dilation
-    *nparts_host = (int)l.grid.x;
+    dw_geometry(n, h, w, c, stride, dilation, &g, &l);
+    if (dilation == 1) *nparts_host = (int)(stride == 1 ? lds_launch<1>(g) : lds_launch<2>(g)).grid.x;   // LDS-tiled kernels
+    else *nparts_host = (int)l.grid.x;                                                                   // gather kernels
     return 0;
 }
 
@@ -374,12 +378,15 @@ int ssdseg_dwconv_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, fl
     // algorithmic traffic: read X, write Y, read W
     const double cost_bytes = 4.0 * ((double)n * h * wdt * c + (double)n * g.ho * g.wo * c + 9.0 * c);
     const double cost_flops = 18.0 * n * g.ho * g.wo * c;
-    if (dilation == 1 && stride == 1)
-        SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_fwd_kernel<1, 1>), l.grid, l.block, l.lds, g, v, w, y, stats);
-    else if (dilation == 1)
-        SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_fwd_kernel<2, 1>), l.grid, l.block, l.lds, g, v, w, y, stats);
-    else
+    if (dilation == 1 && stride == 1) {
+        const LdsLaunch ll = lds_launch<1>(g);
+        SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_fwd_lds_kernel<1>), ll.grid, dim3(256), ll.lds_fwd, g, v, w, y, stats);
+    } else if (dilation == 1) {
+        const LdsLaunch ll = lds_launch<2>(g);
+        SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_fwd_lds_kernel<2>), ll.grid, dim3(256), ll.lds_fwd, g, v, w, y, stats);
+    } else {
         SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_fwd_kernel<1, 0>), l.grid, l.block, l.lds, g, v, w, y, stats);
+    }
     SSDSEG_LAUNCH_CHECK();
     return 0;
 }
@@ -399,8 +406,13 @@ int ssdseg_dwconv_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, co
     DwGeom g;
     DwLaunch l;
     dw_geometry(n, h, wdt, c, stride, dilation, &g, &l);
+    const LdsLaunch ll = stride == 1 ? lds_launch<1>(g) : lds_launch<2>(g);
+    // measured on MI355X (profiles/): the fused LDS backward wins for stride 1 with few channel groups (big early layers,
+    // decoder); with many channel groups or stride 2 its 256-VGPR footprint loses to the register-window kernel
+    const bool use_lds = dilation == 1 && stride == 1 && c <= 160;
+    const int nparts = use_lds ? (int)ll.grid.x : (int)l.grid.x;
     void* ws;
-    size_t part_bytes = (size_t)l.grid.x * 9 * c * sizeof(float);
+    size_t part_bytes = (size_t)nparts * 9 * c * sizeof(float);
     int rc = ssdseg_workspace(ctx, part_bytes, &ws);
     if (rc) return rc;
     float* part = (float*)ws;
@@ -409,17 +421,21 @@ int ssdseg_dwconv_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, co
     // algorithmic traffic: read X, read dY, write dX, read W, write dW
     const double cost_bytes = 4.0 * (2.0 * n * h * wdt * c + (double)n * g.ho * g.wo * c + 18.0 * c);
     const double cost_flops = 36.0 * n * g.ho * g.wo * c;
-#define DW_BWD(S_, D_, PT_, PL_) \
+#define DW_BWD_LDS(S_, PT_, PL_) \
+    SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_bwd_lds_kernel<S_, PT_, PL_>), ll.grid, dim3(256), ll.lds_bwd, g, v, w, gv, dx, part, accumulate)
+#define DW_BWD_REG(S_, D_, PT_, PL_) \
     SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_bwd_kernel<S_, D_, PT_, PL_>), l.grid, l.block, l.lds, g, v, w, gv, dx, part, accumulate)
-    if (dilation != 1) DW_BWD(1, 0, 0, 0);
-    else if (stride == 1) DW_BWD(1, 1, 1, 1);
-    else if (g.pt == 0 && g.pl == 0) DW_BWD(2, 1, 0, 0);
-    else if (g.pt == 0 && g.pl == 1) DW_BWD(2, 1, 0, 1);
-    else if (g.pt == 1 && g.pl == 0) DW_BWD(2, 1, 1, 0);
-    else DW_BWD(2, 1, 1, 1);
-#undef DW_BWD
+    if (dilation != 1) DW_BWD_REG(1, 0, 0, 0);
+    else if (use_lds) DW_BWD_LDS(1, 1, 1);
+    else if (stride == 1) DW_BWD_REG(1, 1, 1, 1);
+    else if (g.pt == 0 && g.pl == 0) DW_BWD_REG(2, 1, 0, 0);
+    else if (g.pt == 0 && g.pl == 1) DW_BWD_REG(2, 1, 0, 1);
+    else if (g.pt == 1 && g.pl == 0) DW_BWD_REG(2, 1, 1, 0);
+    else DW_BWD_REG(2, 1, 1, 1);
+#undef DW_BWD_REG
+#undef DW_BWD_LDS
     SSDSEG_LAUNCH_CHECK();
-    return ssdseg_colsum(ctx, part, (int)l.grid.x, 9LL * c, dw);
+    return ssdseg_colsum(ctx, part, nparts, 9LL * c, dw);
 }
 
 }  // extern "C"

@@ -153,7 +153,7 @@ class DwOp(Op):
         self.w, self.dw = eng.param_view(layer, wname), eng.grad_view(layer, wname)
         s = inp.store
         if eng.training:
-            out.nparts = eng.ctx.parts("ssdseg_dwconv_parts", s.n, s.h, s.w, s.c, stride)
+            out.nparts = eng.ctx.parts("ssdseg_dwconv_parts", s.n, s.h, s.w, s.c, stride, dilation)
             out.stats = eng.ctx.empty((out.nparts, 2, out.c))
         assert s.ld == s.c and out.ld == out.c, "depthwise kernels work on dense (non-sliced) tensors"
         self.out_val: Optional[Val] = None

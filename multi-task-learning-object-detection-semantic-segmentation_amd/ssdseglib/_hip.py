@@ -65,7 +65,7 @@ _SIGNATURES = {
     "ssdseg_stem_conv_parts": [_i, _i, _i, _i, _ip],
     "ssdseg_stem_conv_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp],
     "ssdseg_stem_conv_bwd_weight": [_vp, _vp, _GP, _vp, _vp, _i, _i, _i, _i, _i, _f, _f],
-    "ssdseg_dwconv_parts": [_i, _i, _i, _i, _i, _ip],
+    "ssdseg_dwconv_parts": [_i, _i, _i, _i, _i, _i, _ip],
     "ssdseg_dwconv_fwd": [_vp, _VP, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "ssdseg_dwconv_bwd": [_vp, _VP, _vp, _GP, _vp, _vp, _i, _i, _i, _i, _i, _i, _i],
     "ssdseg_pwconv_parts": [_i, _i, _ip],

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(lib):
 def test_argument_errors_do_not_need_a_device(lib):
     import ctypes as C
     out = C.c_int()
-    assert lib.ssdseg_dwconv_parts(1, 8, 8, 6, 1, C.byref(out)) == -1000 - 4          # channels must be a multiple of 4
+    assert lib.ssdseg_dwconv_parts(1, 8, 8, 6, 1, 1, C.byref(out)) == -1000 - 4       # channels must be a multiple of 4
     assert b"invalid argument 4" in lib.ssdseg_last_error()
     assert lib.ssdseg_pwconv_parts(640, 96, C.byref(out)) == 0 and out.value == 5
     assert lib.ssdseg_stem_conv_parts(2, 480, 640, 32, C.byref(out)) == 0 and out.value > 0

@@ -66,7 +66,7 @@ def test_dwconv_fwd_bwd(ctx, rng, n, h, w, c, s, d, act):
     dx_, dsc, dsh = ctx.array(x), ctx.array(sc), ctx.array(sh)
     dw_ = ctx.array(wgt)
     dy_ = ctx.empty(y_ref.shape)
-    nparts = ctx.parts("ssdseg_dwconv_parts", n, h, w, c, s)
+    nparts = ctx.parts("ssdseg_dwconv_parts", n, h, w, c, s, d)
     stats = ctx.empty((nparts, 2, c))
     ctx.call("ssdseg_dwconv_fwd", H.view(dx_, dsc, dsh, act), dw_, dy_, n, h, w, c, s, d, stats)
     y = dy_.download()
