@@ -266,8 +266,10 @@ int ssdseg_adam_step(ssdseg_ctx* ctx, float* params, const float* grads, float* 
 int ssdseg_maxpool3x3s2_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, float* out, int n, int h, int wdt, int c);
 int ssdseg_maxpool3x3s2_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, const float* g, float* dx, int n, int h, int wdt,
                             int c);
-/* channel shuffle (groups) of a concat of two halves: out[.., j*g + i] = in[.., i*(c/g) + j]  (models.py:497-503) */
-int ssdseg_channel_shuffle(ssdseg_ctx* ctx, const float* in, int ldi, float* out, int ldo, int m, int c, int groups,
+/* channel shuffle (groups) of a concat of two halves: out[.., j*g + i] = view(in)[.., i*(c/g) + j]  (models.py:497-503);
+ * the input is a view, so the lazily fused BatchNorm + ReLU of the concatenated branches is applied in the same pass.
+ * inverse != 0 applies the inverse permutation (gradient path; pass an identity view). */
+int ssdseg_channel_shuffle(ssdseg_ctx* ctx, const ssdseg_view* in, int ldi, float* out, int ldo, int m, int c, int groups,
                            int inverse);
 /* g *= act'(x) in place: backward of a ReLU that follows an Add (ShuffleNetV2 basic unit, models.py:593-595) */
 int ssdseg_act_bwd(ssdseg_ctx* ctx, float* g, int ldg, const float* x, int ldx, int m, int c, int act);

@@ -85,17 +85,20 @@ __global__ void maxpool_bwd_kernel(PoolGeom g, const float* __restrict__ x, cons
 }
 
 // out[m][j*groups + i] = in[m][i*(c/groups) + j]   (Reshape -> Permute(1,2,4,3) -> Reshape); inverse swaps the roles
-__global__ void shuffle_kernel(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo, long long m, int c, int groups,
-                               int inverse) {
+__global__ void shuffle_kernel(const float* __restrict__ in, const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                               int ldi, float* __restrict__ out, int ldo, long long m, int c, int groups, int inverse) {
     const long long total = m * c;
     const int per = c / groups;
+    const float lo = act_lo(act), hi = act_hi(act);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long r = i / c;
         const int k = (int)(i % c);                 // output channel
         int src;
         if (!inverse) src = (k % groups) * per + k / groups;
         else src = (k % per) * groups + k / per;
-        out[r * ldo + k] = in[r * ldi + src];
+        float v = in[r * ldi + src];
+        if (scale != nullptr) v = fmaf(scale[src], v, shift[src]);   // the (lazy) BatchNorm + activation of the shuffled concat
+        out[r * ldo + k] = fminf(fmaxf(v, lo), hi);
     }
 }
 
@@ -152,18 +155,19 @@ int ssdseg_maxpool3x3s2_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, const float*
     return 0;
 }
 
-int ssdseg_channel_shuffle(ssdseg_ctx* ctx, const float* in, int ldi, float* out, int ldo, int m, int c, int groups, int inverse) {
+int ssdseg_channel_shuffle(ssdseg_ctx* ctx, const ssdseg_view* in, int ldi, float* out, int ldo, int m, int c, int groups,
+                           int inverse) {
     SSDSEG_ARG(ctx != nullptr, 1);
-    SSDSEG_ARG(in != nullptr, 2);
+    SSDSEG_ARG(in != nullptr && in->x != nullptr && ((in->scale == nullptr) == (in->shift == nullptr)), 2);
     SSDSEG_ARG(ldi >= c, 3);
-    SSDSEG_ARG(out != nullptr && out != in, 4);
+    SSDSEG_ARG(out != nullptr && out != in->x, 4);
     SSDSEG_ARG(ldo >= c, 5);
     SSDSEG_ARG(m > 0, 6);
     SSDSEG_ARG(c > 0, 7);
     SSDSEG_ARG(groups > 0 && c % groups == 0, 8);
     const long long total = (long long)m * c;
-    SSDSEG_LAUNCH(ctx, 8.0 * total, 0.0, shuffle_kernel, dim3(ew_blocks(total)), dim3(256), 0, in, ldi, out, ldo, (long long)m, c, groups,
-                  inverse);
+    SSDSEG_LAUNCH(ctx, 8.0 * total, 0.0, shuffle_kernel, dim3(ew_blocks(total)), dim3(256), 0, in->x, in->scale, in->shift, in->act, ldi, out,
+                  ldo, (long long)m, c, groups, inverse);
     SSDSEG_LAUNCH_CHECK();
     return 0;
 }

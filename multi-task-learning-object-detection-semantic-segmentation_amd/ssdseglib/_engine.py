@@ -29,6 +29,11 @@ from . import layers as L
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_ZERO = H.ACT_NONE, H.ACT_RELU, H.ACT_RELU6, H.ACT_ZERO
 
 
+def _nonneg(v: "Val") -> bool:
+    """values known to be >= 0 (a ReLU applied on top of them is the identity)"""
+    return v.act in (ACT_RELU, ACT_RELU6, ACT_ZERO) or bool(v.meta.get("nonneg"))
+
+
 def _act_of(relu: K.ReLU) -> int:
     if relu.max_value is None:
         return ACT_RELU
@@ -52,13 +57,16 @@ class Store:
         self.need_grad = need_grad
         self._grad: Optional[H.DeviceBuffer] = None
         self.gwritten = False
+        self.split_parent = False  # channel Split views write disjoint ranges of this gradient: zero it, then everyone accumulates
         self.stats: Optional[H.DeviceBuffer] = None   # per-block (sum, sumsq) partials from the producing conv
         self.nparts = 0
 
     def slice(self, coff: int, c: int, name: str) -> "Store":
         assert coff + c <= self.c
-        return Store(self.eng, self.n, self.h, self.w, c, name, buf=self.buf.view(coff, (self.m * self.ld - coff,)), ld=self.ld,
-                     parent=self, coff=coff, need_grad=self.need_grad)
+        child = Store(self.eng, self.n, self.h, self.w, c, name, buf=self.buf.view(coff, (self.m * self.ld - coff,)), ld=self.ld,
+                      parent=self, coff=coff, need_grad=self.need_grad)
+        self.eng.stores.append(child)      # so its "gradient written" flag is reset with everyone else's each backward pass
+        return child
 
     @property
     def grad(self) -> H.DeviceBuffer:
@@ -130,7 +138,9 @@ class StemOp(Op):
         self.b = eng.param_view(layer, "bias") if layer.use_bias else None
         self.dw = eng.grad_view(layer, "kernel")
         self.db = eng.grad_view(layer, "bias") if layer.use_bias else None
-        if eng.training:
+        if eng.training and self.b is None:
+            # (a biased stem -- ShuffleNetV2, models.py:619 -- gets its batch statistics from a ChannelStatsOp instead: the fused
+            # epilogue relies on padded rows being exactly zero)
             out.nparts = eng.ctx.parts("ssdseg_stem_conv_parts", image.n, image.h, image.w, out.c)
             out.stats = eng.ctx.empty((out.nparts, 2, out.c))
         self.out_val: Optional[Val] = None
@@ -138,11 +148,17 @@ class StemOp(Op):
     def fwd(self):
         i = self.image
         self.e.ctx.call("ssdseg_stem_conv_fwd", i.buf, self.w, self.b, self.out.buf, i.n, i.h, i.w, i.c, self.out.c,
-                        self.rescale[0], self.rescale[1], self.out.stats)
+                        self.rescale[0], self.rescale[1], self.out.stats if self.b is None else None)
 
     def bwd(self):
         i = self.image
-        self.e.ctx.call("ssdseg_stem_conv_bwd_weight", i.buf, self.out_val.gview(), self.dw, self.db, i.n, i.h, i.w, i.c, self.out.c,
+        db = self.db
+        if db is not None and self.out_val.bn is not None:
+            # a bias in front of a training-mode BatchNormalization has an identically zero gradient (the batch mean absorbs
+            # it); the reference's autodiff produces round-off noise there
+            db.zero_()
+            db = None
+        self.e.ctx.call("ssdseg_stem_conv_bwd_weight", i.buf, self.out_val.gview(), self.dw, db, i.n, i.h, i.w, i.c, self.out.c,
                         self.rescale[0], self.rescale[1])
 
 
@@ -273,6 +289,52 @@ class ApplyOp(Op):
             # d(out)/d(activated value) = 1 (the activation mask is applied by the producer's BN/ReLU backward)
             g, acc = v.store.grad_slot()
             self.e.ctx.call("ssdseg_axpby", o.grad, o.ld, g, v.store.ld, o.m, o.c, 1.0, 1.0 if acc else 0.0)
+
+
+class ActBwdOp(Op):
+    """backward-only: g *= act'(x) in place for an activation that sits on a materialised tensor"""
+
+    def __init__(self, eng, store: Store, act: int, name):
+        self.e, self.store, self.act, self.name = eng, store, act, name
+
+    def bwd(self):
+        s = self.store
+        self.e.ctx.call("ssdseg_act_bwd", s.grad, s.ld, s.buf, s.ld, s.m, s.c, self.act)
+
+
+class MaxPoolOp(Op):
+    """MaxPooling2D(3, strides=2, 'same') (reference models.py:629)"""
+
+    def __init__(self, eng, inp: Val, out: Store, name):
+        self.e, self.inp, self.out, self.name = eng, inp, out, name
+
+    def fwd(self):
+        s = self.inp.store
+        self.e.ctx.call("ssdseg_maxpool3x3s2_fwd", self.inp.view(), self.out.buf, s.n, s.h, s.w, s.c)
+
+    def bwd(self):
+        s = self.inp.store
+        if s.need_grad:
+            dx, acc = s.grad_slot()
+            assert acc == 0, "max-pool input with another consumer"
+            self.e.ctx.call("ssdseg_maxpool3x3s2_bwd", self.inp.view(), self.out.grad, dx, s.n, s.h, s.w, s.c)
+
+
+class ShuffleOp(Op):
+    """channel shuffle: Reshape(h, w, g, c/g) -> Permute(1, 2, 4, 3) -> Reshape(h, w, c) (reference models.py:497-503)"""
+
+    def __init__(self, eng, inp: Val, out: Store, groups: int, name):
+        self.e, self.inp, self.out, self.groups, self.name = eng, inp, out, groups, name
+
+    def fwd(self):
+        i, o = self.inp.store, self.out
+        self.e.ctx.call("ssdseg_channel_shuffle", self.inp.view(), i.ld, o.buf, o.ld, i.m, i.c, self.groups, 0)
+
+    def bwd(self):
+        i, o = self.inp.store, self.out
+        g, acc = i.grad_slot()     # gradient w.r.t. the ACTIVATED concat values; the branches' BN backward applies the masks
+        assert acc == 0
+        self.e.ctx.call("ssdseg_channel_shuffle", H.view(o.grad), o.ld, g, i.ld, i.m, i.c, self.groups, 1)
 
 
 class GapOp(Op):
@@ -631,6 +693,12 @@ class Engine:
             if v.bn is not None:
                 assert len(self.cons.get(id(layer.inbound[0]), [])) == 1, f"{layer.name}: BN output feeds both a ReLU and another layer"
                 v.bn.act = act
+            elif act != ACT_NONE:
+                # activation on a materialised tensor (ShuffleNetV2: ReLU after Add, models.py:593-595): consumers clamp on
+                # load; in backward the gradient w.r.t. the activated value is masked in place before the producer runs
+                assert len(self.cons.get(id(layer.inbound[0]), [])) == 1, f"{layer.name}: its input also feeds another layer"
+                if self.training:
+                    self._emit(ActBwdOp(self, v.store, act, layer.name))
             nv = Val(v.store, v.scale, v.shift, act, v.bn)
             prod = getattr(v.store, "producer", None)
             if prod is not None and v.bn is not None:
@@ -658,8 +726,7 @@ class Engine:
         elif isinstance(layer, K.Softmax):
             self._lower_softmax(layer, ins[0], setv)
         elif isinstance(layer, K.Reshape):
-            v = ins[0]
-            setv(Val(v.store, v.scale, v.shift, v.act, v.bn, reshaped=tuple(out_t.shape[1:]), **{k: x for k, x in v.meta.items() if k != "reshaped"}))
+            self._lower_reshape(layer, ins[0], setv)
         elif isinstance(layer, L.DecodeBoxesCentroidsOffsets):
             setv(Val(ins[0].store, decode=layer))
         elif isinstance(layer, L.SegmentationSuppression):
@@ -711,6 +778,7 @@ class Engine:
         parent = self._concat_parts(layer)
         acts = set()
         off = 0
+        copied_nonneg = True
         for t, v in zip(layer.inbound, ins):
             c = t.shape[-1]
             if v.store.parent is parent and v.store.coff == off:
@@ -720,9 +788,14 @@ class Engine:
                 sl = parent.slice(off, c, f"{layer.name}[{off}:{off + c}]")
                 self._emit(ApplyOp(self, v, None, sl, f"{layer.name}:copy{off}"))
                 acts.add(None)
+                copied_nonneg = copied_nonneg and _nonneg(v)
             off += c
         real = {a for a in acts if a is not None}
-        if None in acts:
+        if None in acts and real == {ACT_RELU} and copied_nonneg:
+            # ShuffleNetV2 basic unit (models.py:573-598): the untouched half holds values >= 0 (it comes out of a ReLU'd
+            # shuffle / max-pool), so the other half's lazy ReLU is the identity on it and the concat can stay a view
+            setv(Val(parent, parent.wide_scale, parent.wide_shift, ACT_RELU))
+        elif None in acts:
             # copied slices hold final values: only legal to keep lazy activations if there are none left
             assert not real or real == {ACT_NONE}, f"{layer.name}: cannot mix copied and lazily-activated inputs"
             setv(Val(parent))
@@ -753,7 +826,39 @@ class Engine:
             raise NotImplementedError(f"{layer.name}: Softmax on this tensor kind")
 
     def _lower_shufflenet(self, layer, ins, setv):
-        raise NotImplementedError(f"layer type {type(layer).__name__} ({layer.name}) is not lowered yet")
+        """ShuffleNetV2-only layers (reference models.py:480-652): max-pool, channel split, channel shuffle"""
+        out_t = layer.outputs[0]
+        if isinstance(layer, K.MaxPooling2D):
+            st = self._out_store(layer, out_t.shape)
+            self._emit(MaxPoolOp(self, self._dense(ins[0], layer.name), st, layer.name))
+            setv(Val(st, nonneg=_nonneg(ins[0])))
+        elif isinstance(layer, L.Split):
+            v = ins[0]
+            assert v.scale is None and v.act == ACT_NONE and layer.axis in (-1, 3), f"{layer.name}: only plain channel splits are lowered"
+            v.store.split_parent = True
+            off = 0
+            for t in layer.outputs:
+                c = t.shape[-1]
+                self.vals[id(t)] = Val(v.store.slice(off, c, f"{layer.name}[{off}:{off + c}]"), nonneg=_nonneg(v))   # zero-copy channel view
+                off += c
+        elif isinstance(layer, K.Permute):
+            v = ins[0]
+            assert v.meta.get("shuffle_groups") and layer.dims == (1, 2, 4, 3), f"{layer.name}: only the channel-shuffle Permute is lowered"
+            setv(Val(v.store, shuffle_groups=v.meta["shuffle_groups"], shuffle_src=v.meta["shuffle_src"], shuffle_permuted=True))
+        else:
+            raise NotImplementedError(f"layer type {type(layer).__name__} ({layer.name}) is not lowered yet")
+
+    def _lower_reshape(self, layer: K.Reshape, v: Val, setv):
+        out_t = layer.outputs[0]
+        tgt = tuple(out_t.shape[1:])
+        if len(tgt) == 4:                          # (h, w, groups, c/groups): first half of a channel shuffle (models.py:497)
+            setv(Val(v.store, v.scale, v.shift, v.act, v.bn, shuffle_groups=tgt[2], shuffle_src=v))
+        elif v.meta.get("shuffle_permuted"):       # back to (h, w, c): emit the shuffle (models.py:503)
+            st = self._out_store(layer, out_t.shape)
+            self._emit(ShuffleOp(self, v.meta["shuffle_src"], st, v.meta["shuffle_groups"], layer.name))
+            setv(Val(st, nonneg=_nonneg(v.meta["shuffle_src"])))
+        else:                                      # SSD heads: (B, H, W, boxes*4) -> (B, H*W*boxes, 4), metadata only
+            setv(Val(v.store, v.scale, v.shift, v.act, v.bn, reshaped=tgt, **{k: x for k, x in v.meta.items() if k != "reshaped"}))
 
     keep_mask_probabilities = False
 
@@ -774,6 +879,10 @@ class Engine:
     def backward(self):
         for s in self.stores:
             s.gwritten = False
+        for s in self.stores:
+            if s.split_parent and s.need_grad:
+                s.grad.zero_()
+                s.gwritten = True
         for op in reversed(self.ops):
             op.bwd()
 

@@ -101,7 +101,7 @@ _SIGNATURES = {
     "ssdseg_adam_step": [_vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _i, _f],
     "ssdseg_maxpool3x3s2_fwd": [_vp, _VP, _vp, _i, _i, _i, _i],
     "ssdseg_maxpool3x3s2_bwd": [_vp, _VP, _vp, _vp, _i, _i, _i, _i],
-    "ssdseg_channel_shuffle": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i],
+    "ssdseg_channel_shuffle": [_vp, _VP, _i, _vp, _i, _i, _i, _i, _i],
 }
 
 

@@ -191,7 +191,7 @@ class NpModel:
                 parts = [o if o is not None else np.zeros_like(self.vals[id(t)]) for o, t in zip(outs, l.outputs)]
                 acc(l.inbound[0], np.concatenate(parts, axis=l.axis))
             elif k == "MaxPooling2D":
-                raise NotImplementedError("maxpool backward: see np_ops (ShuffleNetV2 round)")
+                acc(l.inbound[0], O.maxpool3x3s2_bwd(ins[0], go))
             else:
                 raise NotImplementedError(k)
         return grads

@@ -283,11 +283,14 @@ def test_maxpool_shuffle_actbwd_dice(ctx, rng):
     ctx.call("ssdseg_maxpool3x3s2_bwd", H.view(dx_), ctx.array(g), dx, n, h, w, c)
     assert np.abs(dx.download() - O.maxpool3x3s2_bwd(x, g)).max() < 1e-6
     sh = ctx.empty(x.shape)
-    ctx.call("ssdseg_channel_shuffle", dx_, c, sh, c, n * h * w, c, 2, 0)
+    ctx.call("ssdseg_channel_shuffle", H.view(dx_), c, sh, c, n * h * w, c, 2, 0)
     assert np.array_equal(sh.download(), O.channel_shuffle(x, 2))
     back = ctx.empty(x.shape)
-    ctx.call("ssdseg_channel_shuffle", sh, c, back, c, n * h * w, c, 2, 1)
+    ctx.call("ssdseg_channel_shuffle", H.view(sh), c, back, c, n * h * w, c, 2, 1)
     assert np.array_equal(back.download(), x)
+    sc, sf = rng.uniform(0.5, 1.5, c).astype(np.float32), rng.normal(0, 0.3, c).astype(np.float32)
+    ctx.call("ssdseg_channel_shuffle", H.view(dx_, ctx.array(sc), ctx.array(sf), O.ACT_RELU), c, sh, c, n * h * w, c, 2, 0)   # fused BN + ReLU
+    assert np.abs(sh.download() - O.channel_shuffle(np.maximum(x * sc + sf, 0), 2)).max() < 1e-6
     gg = ctx.array(g_full := rng.normal(0, 1, x.shape).astype(np.float32))
     ctx.call("ssdseg_act_bwd", gg, c, dx_, c, n * h * w, c, O.ACT_RELU)
     assert np.array_equal(gg.download(), g_full * (x > 0))
