@@ -7,43 +7,78 @@ namespace {
 
 constexpr int MAX_PARTS = 1024;
 
-constexpr int RC = 32;   // channels per block of the partial-row reductions
-constexpr int RP = 32;   // partial rows summed in parallel per channel
+// Partial-row reductions: blocks of RC channels x RP lanes along the partial rows (RC * RP == 1024).  A table with many
+// rows and few channels (BN partials of a 16..160-channel tensor: up to 2048 rows) would otherwise run on c/32 blocks with
+// 64 dependent loads per thread; the narrow shape gives 4x the blocks and 4x fewer serial loads.
+constexpr int RTHREADS = 1024;
 
-// Sums part[p][v][ch] over p for v < NV: 32 lanes along p per channel, fp64, fixed order (deterministic).
-// Result valid for threadIdx.y == 0.  red: NV * RP * (RC + 1) doubles of LDS.
-template <int NV>
+// Sums part[p][v][ch] over p for v < NV: RP lanes along p per channel, 4 independent fp64 chains per lane, then a fixed-
+// order fold (deterministic).  Result valid for threadIdx.y == 0.  red: NV * RP * (RC + 1) doubles of LDS.
+template <int NV, int RC>
 __device__ __forceinline__ void reduce_parts(const float* __restrict__ part, int nparts, int c, int ch, double (&tot)[NV], double* red) {
-    double acc[NV];
+    constexpr int RP = RTHREADS / RC;
+    double acc[NV][4];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[v][u] = 0.0;
     if (ch < c) {
-        for (int p = threadIdx.y; p < nparts; p += RP) {
+        int p = threadIdx.y;
+        for (; p + 3 * RP < nparts; p += 4 * RP) {
+            float f[NV][4];
 #pragma unroll
-            for (int v = 0; v < NV; ++v) acc[v] += (double)part[((long long)p * NV + v) * c + ch];
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < NV; ++v) f[v][u] = part[((long long)(p + u * RP) * NV + v) * c + ch];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < NV; ++v) acc[v][u] += (double)f[v][u];
+        }
+        for (; p < nparts; p += RP) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) acc[v][0] += (double)part[((long long)p * NV + v) * c + ch];
         }
     }
 #pragma unroll
-    for (int v = 0; v < NV; ++v) red[(v * RP + threadIdx.y) * (RC + 1) + threadIdx.x] = acc[v];
+    for (int v = 0; v < NV; ++v) red[(v * RP + threadIdx.y) * (RC + 1) + threadIdx.x] = (acc[v][0] + acc[v][1]) + (acc[v][2] + acc[v][3]);
     __syncthreads();
+    // fold RP -> 8 lanes in parallel, then serially (fixed order either way)
+    for (int half = RP / 2; half >= 8; half >>= 1) {
+        if ((int)threadIdx.y < half) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                red[(v * RP + threadIdx.y) * (RC + 1) + threadIdx.x] += red[(v * RP + threadIdx.y + half) * (RC + 1) + threadIdx.x];
+        }
+        __syncthreads();
+    }
     if (threadIdx.y == 0) {
+        constexpr int LAST = RP < 8 ? RP : 8;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             double s = 0.0;
-            for (int y = 0; y < RP; ++y) s += red[(v * RP + y) * (RC + 1) + threadIdx.x];
+            for (int y = 0; y < LAST; ++y) s += red[(v * RP + y) * (RC + 1) + threadIdx.x];
             tot[v] = s;
         }
     }
 }
 
-__global__ void __launch_bounds__(RC * RP) bn_finalize_kernel(const float* __restrict__ stats, int nparts, int c, double count,
+// channels per block for a table of nparts rows
+// (narrow blocks read 32-byte row segments, so they are only worth it while the table is too narrow to fill the chip)
+inline int reduce_rc(int nparts, long long len) {
+    if (nparts < 32) return 128;
+    return (nparts >= 256 && len < 2048) ? 8 : 32;
+}
+
+template <int RC>
+__global__ void __launch_bounds__(RTHREADS) bn_finalize_kernel(const float* __restrict__ stats, int nparts, int c, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
                                    float* __restrict__ moving_mean, float* __restrict__ moving_var, float* __restrict__ mean_out,
                                    float* __restrict__ invstd_out, float* __restrict__ scale, float* __restrict__ shift, int training) {
-    __shared__ double red[2 * RP * (RC + 1)];
+    __shared__ double red[2 * (RTHREADS / RC) * (RC + 1)];
     const int ch = blockIdx.x * RC + threadIdx.x;
     double tot[2] = {0.0, 0.0};
-    if (training) reduce_parts<2>(stats, nparts, c, ch, tot, red);
+    if (training) reduce_parts<2, RC>(stats, nparts, c, ch, tot, red);
     if (threadIdx.y != 0 || ch >= c) return;
     double mean, var;
     if (training) {
@@ -140,13 +175,14 @@ __global__ void __launch_bounds__(512) bn_bwd_partial_kernel(const float* __rest
     }
 }
 
-__global__ void __launch_bounds__(RC * RP) bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int c, double count,
+template <int RC>
+__global__ void __launch_bounds__(RTHREADS) bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int c, double count,
                                        const float* __restrict__ scale, const float* __restrict__ mean, const float* __restrict__ invstd,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ k1, float* __restrict__ k0) {
-    __shared__ double red[2 * RP * (RC + 1)];
+    __shared__ double red[2 * (RTHREADS / RC) * (RC + 1)];
     const int ch = blockIdx.x * RC + threadIdx.x;
     double tot[2] = {0.0, 0.0};
-    reduce_parts<2>(part, nparts, c, ch, tot, red);
+    reduce_parts<2, RC>(part, nparts, c, ch, tot, red);
     if (threadIdx.y != 0 || ch >= c) return;
     const double db = tot[0], dg = tot[1];
     if (dgamma) dgamma[ch] = (float)dg;
@@ -157,11 +193,12 @@ __global__ void __launch_bounds__(RC * RP) bn_bwd_finalize_kernel(const float* _
 }
 
 // out[l] = sum_p part[p][l]
-__global__ void __launch_bounds__(RC * RP) colsum_kernel(const float* __restrict__ part, int nparts, int len, float* __restrict__ out) {
-    __shared__ double red[RP * (RC + 1)];
+template <int RC>
+__global__ void __launch_bounds__(RTHREADS) colsum_kernel(const float* __restrict__ part, int nparts, int len, float* __restrict__ out) {
+    __shared__ double red[(RTHREADS / RC) * (RC + 1)];
     const int l = blockIdx.x * RC + threadIdx.x;
     double tot[1] = {0.0};
-    reduce_parts<1>(part, nparts, len, l, tot, red);
+    reduce_parts<1, RC>(part, nparts, len, l, tot, red);
     if (threadIdx.y == 0 && l < len) out[l] = (float)tot[0];
 }
 
@@ -228,8 +265,27 @@ int ew_blocks(long long total) {
 }  // namespace
 
 // shared with other translation units: out[l] = sum over nparts rows of part[p][l]
+int ssdseg_bn_bwd_finalize_launch(ssdseg_ctx* ctx, const float* part, int nparts, int c, double count, const float* scale,
+                                  const float* mean, const float* invstd, float* dgamma, float* dbeta, float* k1, float* k0) {
+    const int rcw = reduce_rc(nparts, c);
+    const dim3 fgrid(cdiv(c, rcw)), fblock(rcw, RTHREADS / rcw);
+#define SSDSEG_BNBF(RCV)                                                                                                              \
+    SSDSEG_LAUNCH_NAMED(ctx, "bn_bwd_finalize_kernel", 8.0 * nparts * c, 0.0, bn_bwd_finalize_kernel<RCV>, fgrid, fblock, 0, part, nparts, c, \
+                        count, scale, mean, invstd, dgamma, dbeta, k1, k0)
+    if (rcw == 8) SSDSEG_BNBF(8);
+    else if (rcw == 32) SSDSEG_BNBF(32);
+    else SSDSEG_BNBF(128);
+#undef SSDSEG_BNBF
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
+}
+
 int ssdseg_colsum(ssdseg_ctx* ctx, const float* part, int nparts, long long len, float* out) {
-    SSDSEG_LAUNCH(ctx, 4.0 * nparts * len, 0.0, colsum_kernel, dim3(cdiv(len, RC)), dim3(RC, RP), 0, part, nparts, (int)len, out);
+    const int rc = reduce_rc(nparts, len);
+    const dim3 grid(cdiv(len, rc)), block(rc, RTHREADS / rc);
+    if (rc == 8) SSDSEG_LAUNCH_NAMED(ctx, "colsum_kernel", 4.0 * nparts * len, 0.0, colsum_kernel<8>, grid, block, 0, part, nparts, (int)len, out);
+    else if (rc == 32) SSDSEG_LAUNCH_NAMED(ctx, "colsum_kernel", 4.0 * nparts * len, 0.0, colsum_kernel<32>, grid, block, 0, part, nparts, (int)len, out);
+    else SSDSEG_LAUNCH_NAMED(ctx, "colsum_kernel", 4.0 * nparts * len, 0.0, colsum_kernel<128>, grid, block, 0, part, nparts, (int)len, out);
     SSDSEG_LAUNCH_CHECK();
     return 0;
 }
@@ -249,8 +305,15 @@ int ssdseg_bn_finalize(ssdseg_ctx* ctx, const float* stats, int nparts, int c, d
     SSDSEG_ARG((moving_mean == nullptr) == (moving_var == nullptr), 11);
     SSDSEG_ARG(scale != nullptr, 14);
     SSDSEG_ARG(shift != nullptr, 15);
-    SSDSEG_LAUNCH(ctx, 8.0 * nparts * c, 0.0, bn_finalize_kernel, dim3(cdiv(c, RC)), dim3(RC, RP), 0, stats, nparts, c, count, gamma, beta, eps,
-                  momentum, moving_mean, moving_var, mean, invstd, scale, shift, training);
+    const int rc = training ? reduce_rc(nparts, c) : 128;
+    const dim3 grid(cdiv(c, rc)), block(rc, RTHREADS / rc);
+#define SSDSEG_BNF(RCV)                                                                                                                     \
+    SSDSEG_LAUNCH_NAMED(ctx, "bn_finalize_kernel", 8.0 * nparts * c, 0.0, bn_finalize_kernel<RCV>, grid, block, 0, stats, nparts, c, count, gamma, \
+                        beta, eps, momentum, moving_mean, moving_var, mean, invstd, scale, shift, training)
+    if (rc == 8) SSDSEG_BNF(8);
+    else if (rc == 32) SSDSEG_BNF(32);
+    else SSDSEG_BNF(128);
+#undef SSDSEG_BNF
     SSDSEG_LAUNCH_CHECK();
     return 0;
 }
@@ -321,10 +384,7 @@ int ssdseg_bn_bwd_reduce(ssdseg_ctx* ctx, const float* g, int ldg, const float* 
     SSDSEG_LAUNCH(ctx, 8.0 * m * c, 0.0, bn_bwd_partial_kernel, l.grid, l.block, l.lds, g, ldg, y, ldy, rg, scale, shift, mean, invstd, act,
                        (float*)ws);
     SSDSEG_LAUNCH_CHECK();
-    SSDSEG_LAUNCH(ctx, 8.0 * l.grid.x * c, 0.0, bn_bwd_finalize_kernel, dim3(cdiv(c, RC)), dim3(RC, RP), 0, (const float*)ws, (int)l.grid.x, c, (double)m,
-                       scale, mean, invstd, dgamma, dbeta, k1, k0);
-    SSDSEG_LAUNCH_CHECK();
-    return 0;
+    return ssdseg_bn_bwd_finalize_launch(ctx, (const float*)ws, (int)l.grid.x, c, (double)m, scale, mean, invstd, dgamma, dbeta, k1, k0);
 }
 
 int ssdseg_axpby(ssdseg_ctx* ctx, const float* src, int lds, float* dst, int ldd, int m, int c, float a, float b) {

@@ -123,6 +123,26 @@ __device__ __forceinline__ float4 gview_apply4(float4 g, float4 y, float4 s, flo
     return r;
 }
 
+// XCD-aware block -> work mapping.  Workgroups are handed to the 8 XCDs round-robin in launch order and every XCD has its
+// own 4 MiB L2, so blocks b, b+1 (neighbouring tiles) never share an L2 and a 3x3 stencil's halo rows are fetched from HBM
+// once per XCD (measured with FETCH_SIZE: 5x the algorithmic bytes on the register-window depthwise backward).  Remapped,
+// XCD k walks the contiguous range [k*total/8, (k+1)*total/8) of the (x fastest, then y) logical grid, so spatial neighbours
+// are resident on the same L2 at the same time.  A speed-only affinity: any mapping is correct.  Needs total % 8 == 0
+// (launchers round grid.x up to a multiple of 8), otherwise the identity.
+struct BlockPos {
+    int x, y;
+};
+__device__ __forceinline__ BlockPos xcd_block_pos() {
+    BlockPos p;
+    const unsigned total = gridDim.x * gridDim.y;
+    const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+    unsigned logical = lin;
+    if ((total & 7u) == 0u) logical = (lin & 7u) * (total >> 3) + (lin >> 3);
+    p.y = (int)(logical / gridDim.x);
+    p.x = (int)(logical - (unsigned)p.y * gridDim.x);
+    return p;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

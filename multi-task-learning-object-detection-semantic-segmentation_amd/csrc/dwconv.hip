@@ -83,7 +83,8 @@ template <int S, int DIL>
 __global__ void __launch_bounds__(512) dw_fwd_kernel(DwGeom gm, ViewDev in, const float* __restrict__ wgt,
                                                      float* __restrict__ y, float* __restrict__ stats) {
     extern __shared__ float4 red[];
-    const int cvi = blockIdx.y * blockDim.x + threadIdx.x;
+    const BlockPos bpos = xcd_block_pos();   // (tile slot, channel group), neighbouring slots on the same XCD / L2
+    const int cvi = bpos.y * blockDim.x + threadIdx.x;
     const bool active = cvi < gm.cv;
     const int c0 = cvi * 4;
     float4 wk[9];
@@ -100,7 +101,7 @@ __global__ void __launch_bounds__(512) dw_fwd_kernel(DwGeom gm, ViewDev in, cons
     }
     float4 ssum = f4(0.f), ssq = f4(0.f);
     if (active) {
-        for (long long tile = (long long)blockIdx.x * blockDim.y + threadIdx.y; tile < gm.ntiles;
+        for (long long tile = (long long)bpos.x * blockDim.y + threadIdx.y; tile < gm.ntiles;
              tile += (long long)gridDim.x * blockDim.y) {
             const int wt = (int)(tile % gm.wtiles);
             const long long r = tile / gm.wtiles;
@@ -160,7 +161,7 @@ __global__ void __launch_bounds__(512) dw_fwd_kernel(DwGeom gm, ViewDev in, cons
         float4 a = reduce_over_y(ssum, red);
         float4 b = reduce_over_y(ssq, red);
         if (threadIdx.y == 0 && active) {
-            float* row = stats + (long long)blockIdx.x * 2 * gm.c;
+            float* row = stats + (long long)bpos.x * 2 * gm.c;
             st4(row + c0, a);
             st4(row + gm.c + c0, b);
         }
@@ -175,7 +176,8 @@ template <int S, int DIL, int PT, int PL>
 __global__ void __launch_bounds__(512) dw_bwd_kernel(DwGeom gm, ViewDev in, const float* __restrict__ wgt, GViewDev dy,
                                                      float* __restrict__ dx, float* __restrict__ dwpart, int accumulate) {
     extern __shared__ float4 red[];
-    const int cvi = blockIdx.y * blockDim.x + threadIdx.x;
+    const BlockPos bpos = xcd_block_pos();   // (tile slot, channel group), neighbouring slots on the same XCD / L2
+    const int cvi = bpos.y * blockDim.x + threadIdx.x;
     const bool active = cvi < gm.cv;
     const int c0 = cvi * 4;
     ChanCoef ci, co;  // input-side view coefficients, output-side gradient-view coefficients
@@ -195,7 +197,7 @@ __global__ void __launch_bounds__(512) dw_bwd_kernel(DwGeom gm, ViewDev in, cons
     for (int t = 0; t < 9; ++t) dwacc[t] = f4(0.f);
 
     if (active) {
-        for (long long tile = (long long)blockIdx.x * blockDim.y + threadIdx.y; tile < gm.ntiles;
+        for (long long tile = (long long)bpos.x * blockDim.y + threadIdx.y; tile < gm.ntiles;
              tile += (long long)gridDim.x * blockDim.y) {
             const int wt = (int)(tile % gm.wtiles);
             const long long r = tile / gm.wtiles;
@@ -307,7 +309,7 @@ __global__ void __launch_bounds__(512) dw_bwd_kernel(DwGeom gm, ViewDev in, cons
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         float4 v = reduce_over_y(dwacc[t], red);
-        if (threadIdx.y == 0 && active) st4(dwpart + ((long long)blockIdx.x * 9 + t) * gm.c + c0, v);
+        if (threadIdx.y == 0 && active) st4(dwpart + ((long long)bpos.x * 9 + t) * gm.c + c0, v);
     }
 }
 
@@ -330,6 +332,7 @@ bool dw_geometry(int n, int h, int w, int c, int stride, int dilation, DwGeom* g
     long long want = (g->ntiles + by - 1) / by;
     int gx = (int)(want < MAX_BLOCKS ? want : MAX_BLOCKS);
     if (gx < 1) gx = 1;
+    gx = (gx + 7) & ~7;   // multiple of 8 for the XCD remap (surplus blocks find no tile and write zero partial rows)
     l->block = dim3(bx, by, 1);
     l->grid = dim3(gx, cdiv(g->cv, bx), 1);
     l->lds = (size_t)bx * by * sizeof(float4);
@@ -339,8 +342,98 @@ bool dw_geometry(int n, int h, int w, int c, int stride, int dilation, DwGeom* g
 }  // namespace
 
 #include "dwconv_lds.h"
+#include "dwconv_march.h"
+
+#include <stdlib.h>
 
 int ssdseg_colsum(ssdseg_ctx* ctx, const float* part, int nparts, long long len, float* out);  // bn.hip
+// bn.hip: (dgamma, dbeta, k1, k0) from nparts partial rows of (sum mask*g, sum mask*g*xhat)
+int ssdseg_bn_bwd_finalize_launch(ssdseg_ctx* ctx, const float* part, int nparts, int c, double count, const float* scale,
+                                  const float* mean, const float* invstd, float* dgamma, float* dbeta, float* k1, float* k0);
+
+namespace {
+
+// SSDSEG_DW_BWD=march|lds|reg forces one backward kernel family (A/B measurements); default: measured best per shape
+int dw_bwd_choice() {
+    static int choice = -1;
+    if (choice < 0) {
+        const char* e = getenv("SSDSEG_DW_BWD");
+        choice = !e ? 0 : (!strcmp(e, "march") ? 1 : (!strcmp(e, "lds") ? 2 : (!strcmp(e, "reg") ? 3 : 0)));
+    }
+    return choice;
+}
+
+struct BnFuse {   // BatchNorm-backward reduction of the layer feeding this depthwise conv, fused into its backward
+    const float* mean;
+    const float* invstd;
+    float *dgamma, *dbeta, *k1, *k0;
+};
+
+int dw_bwd_impl(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, const ssdseg_gview* dy, float* dx, float* dw, int n, int h,
+                int wdt, int c, int stride, int dilation, int accumulate, const BnFuse* bn, bool* bn_done) {
+    DwGeom g;
+    DwLaunch l;
+    dw_geometry(n, h, wdt, c, stride, dilation, &g, &l);
+    ViewDev v{in->x, in->scale, in->shift, in->act};
+    GViewDev gv{dy->g, dy->y, dy->scale, dy->shift, dy->k1, dy->k0, dy->act};
+    // algorithmic traffic (SURVEY.md 8d): read X, read dY, write dX, read W, write dW
+    const double cost_bytes = 4.0 * (2.0 * n * h * wdt * c + (double)n * g.ho * g.wo * c + 18.0 * c);
+    const double cost_flops = 36.0 * n * g.ho * g.wo * c;
+    const int choice = dw_bwd_choice();
+    const bool march_ok = dilation == 1 && stride == 1 && (long long)n * h * wdt * c < (1LL << 31);
+    if (bn_done) *bn_done = false;
+    if (march_ok && (choice == 0 || choice == 1)) {
+        MarchGeom mg;
+        const MarchLaunch ml = march_geometry(n, h, wdt, c, &mg);
+        const int nparts = (int)ml.grid.x;
+        const bool fuse = bn != nullptr && !accumulate;
+        void* ws;
+        int rc = ssdseg_workspace(ctx, (size_t)nparts * 11 * c * sizeof(float), &ws);
+        if (rc) return rc;
+        float* part = (float*)ws;
+        float* bnpart = part + (size_t)nparts * 9 * c;
+        if (fuse) {
+            SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_bwd_march_kernel<true>), ml.grid, ml.block, ml.lds, mg, v, w, gv, dx, part, accumulate,
+                          bn->mean, bn->invstd, bnpart);
+        } else {
+            SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_bwd_march_kernel<false>), ml.grid, ml.block, ml.lds, mg, v, w, gv, dx, part, accumulate,
+                          (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
+        }
+        SSDSEG_LAUNCH_CHECK();
+        rc = ssdseg_colsum(ctx, part, nparts, 9LL * c, dw);
+        if (rc || !fuse) return rc;
+        *bn_done = true;
+        return ssdseg_bn_bwd_finalize_launch(ctx, bnpart, nparts, c, (double)n * h * wdt, in->scale, bn->mean, bn->invstd, bn->dgamma,
+                                             bn->dbeta, bn->k1, bn->k0);
+    }
+    const LdsLaunch ll = stride == 1 ? lds_launch<1>(g) : lds_launch<2>(g);
+    // measured on MI355X (profiles/): the fused LDS backward wins for stride 1 with few channel groups (big early layers,
+    // decoder); with many channel groups or stride 2 its 256-VGPR footprint loses to the register-window kernel
+    const bool use_lds = dilation == 1 && stride == 1 && (choice == 2 || (choice != 3 && c <= 160));
+    const int nparts = use_lds ? (int)ll.grid.x : (int)l.grid.x;
+    void* ws;
+    size_t part_bytes = (size_t)nparts * 9 * c * sizeof(float);
+    int rc = ssdseg_workspace(ctx, part_bytes, &ws);
+    if (rc) return rc;
+    float* part = (float*)ws;
+#define DW_BWD_LDS(S_, PT_, PL_) \
+    SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_bwd_lds_kernel<S_, PT_, PL_>), ll.grid, dim3(256), ll.lds_bwd, g, v, w, gv, dx, part, accumulate)
+#define DW_BWD_REG(S_, D_, PT_, PL_) \
+    SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_bwd_kernel<S_, D_, PT_, PL_>), l.grid, l.block, l.lds, g, v, w, gv, dx, part, accumulate)
+    if (dilation != 1) DW_BWD_REG(1, 0, 0, 0);
+    else if (use_lds) DW_BWD_LDS(1, 1, 1);
+    else if (stride == 1) DW_BWD_REG(1, 1, 1, 1);
+    else if (g.pt == 0 && g.pl == 0) DW_BWD_REG(2, 1, 0, 0);
+    else if (g.pt == 0 && g.pl == 1) DW_BWD_REG(2, 1, 0, 1);
+    else if (g.pt == 1 && g.pl == 0) DW_BWD_REG(2, 1, 1, 0);
+    else DW_BWD_REG(2, 1, 1, 1);
+#undef DW_BWD_REG
+#undef DW_BWD_LDS
+    SSDSEG_LAUNCH_CHECK();
+    return ssdseg_colsum(ctx, part, nparts, 9LL * c, dw);
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -403,39 +496,32 @@ int ssdseg_dwconv_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, co
     SSDSEG_ARG(c > 0 && c % 4 == 0, 10);
     SSDSEG_ARG(stride == 1 || stride == 2, 11);
     SSDSEG_ARG(dilation >= 1 && (dilation == 1 || stride == 1), 12);
-    DwGeom g;
-    DwLaunch l;
-    dw_geometry(n, h, wdt, c, stride, dilation, &g, &l);
-    const LdsLaunch ll = stride == 1 ? lds_launch<1>(g) : lds_launch<2>(g);
-    // measured on MI355X (profiles/): the fused LDS backward wins for stride 1 with few channel groups (big early layers,
-    // decoder); with many channel groups or stride 2 its 256-VGPR footprint loses to the register-window kernel
-    const bool use_lds = dilation == 1 && stride == 1 && c <= 160;
-    const int nparts = use_lds ? (int)ll.grid.x : (int)l.grid.x;
-    void* ws;
-    size_t part_bytes = (size_t)nparts * 9 * c * sizeof(float);
-    int rc = ssdseg_workspace(ctx, part_bytes, &ws);
-    if (rc) return rc;
-    float* part = (float*)ws;
-    ViewDev v{in->x, in->scale, in->shift, in->act};
-    GViewDev gv{dy->g, dy->y, dy->scale, dy->shift, dy->k1, dy->k0, dy->act};
-    // algorithmic traffic (SURVEY.md 8d): read X, read dY, write dX, read W, write dW
-    const double cost_bytes = 4.0 * (2.0 * n * h * wdt * c + (double)n * g.ho * g.wo * c + 18.0 * c);
-    const double cost_flops = 36.0 * n * g.ho * g.wo * c;
-#define DW_BWD_LDS(S_, PT_, PL_) \
-    SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_bwd_lds_kernel<S_, PT_, PL_>), ll.grid, dim3(256), ll.lds_bwd, g, v, w, gv, dx, part, accumulate)
-#define DW_BWD_REG(S_, D_, PT_, PL_) \
-    SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_bwd_kernel<S_, D_, PT_, PL_>), l.grid, l.block, l.lds, g, v, w, gv, dx, part, accumulate)
-    if (dilation != 1) DW_BWD_REG(1, 0, 0, 0);
-    else if (use_lds) DW_BWD_LDS(1, 1, 1);
-    else if (stride == 1) DW_BWD_REG(1, 1, 1, 1);
-    else if (g.pt == 0 && g.pl == 0) DW_BWD_REG(2, 1, 0, 0);
-    else if (g.pt == 0 && g.pl == 1) DW_BWD_REG(2, 1, 0, 1);
-    else if (g.pt == 1 && g.pl == 0) DW_BWD_REG(2, 1, 1, 0);
-    else DW_BWD_REG(2, 1, 1, 1);
-#undef DW_BWD_REG
-#undef DW_BWD_LDS
-    SSDSEG_LAUNCH_CHECK();
-    return ssdseg_colsum(ctx, part, nparts, 9LL * c, dw);
+    return dw_bwd_impl(ctx, in, w, dy, dx, dw, n, h, wdt, c, stride, dilation, accumulate, nullptr, nullptr);
+}
+
+int ssdseg_dwconv_bwd_bn(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, const ssdseg_gview* dy, float* dx, float* dw, int n,
+                         int h, int wdt, int c, int stride, int dilation, const float* in_mean, const float* in_invstd,
+                         float* in_dgamma, float* in_dbeta, float* in_k1, float* in_k0) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(in != nullptr && in->x != nullptr && in->scale != nullptr && in->shift != nullptr, 2);
+    SSDSEG_ARG(w != nullptr, 3);
+    SSDSEG_ARG(dy != nullptr && dy->g != nullptr, 4);
+    SSDSEG_ARG(dy->scale == nullptr || (dy->y && dy->shift && dy->k1 && dy->k0), 4);
+    SSDSEG_ARG(dx != nullptr, 5);
+    SSDSEG_ARG(dw != nullptr, 6);
+    SSDSEG_ARG(n > 0 && h > 0 && wdt > 0, 7);
+    SSDSEG_ARG(c > 0 && c % 4 == 0, 10);
+    SSDSEG_ARG(stride == 1 || stride == 2, 11);
+    SSDSEG_ARG(dilation >= 1 && (dilation == 1 || stride == 1), 12);
+    SSDSEG_ARG(in_mean != nullptr && in_invstd != nullptr, 13);
+    SSDSEG_ARG(in_k1 != nullptr && in_k0 != nullptr, 17);
+    const BnFuse bn{in_mean, in_invstd, in_dgamma, in_dbeta, in_k1, in_k0};
+    bool done = false;
+    int rc = dw_bwd_impl(ctx, in, w, dy, dx, dw, n, h, wdt, c, stride, dilation, 0, &bn, &done);
+    if (rc || done) return rc;
+    // shapes without a fused kernel: the same reduction as a separate pass over (dx, x)
+    return ssdseg_bn_bwd_reduce(ctx, dx, c, in->x, c, n * h * wdt, c, in->scale, in->shift, in_mean, in_invstd, in->act, in_dgamma, in_dbeta,
+                                in_k1, in_k0);
 }
 
 }  // extern "C"

@@ -6,7 +6,7 @@
 // independent loads per thread -- and computes from LDS (ds_read_b128).  Each input is fetched ~1.3x (halo) instead of
 // ~4.5x.  The producer's BatchNorm+ReLU6 (or the BN-backward gradient view) is applied once per element on the way into LDS.
 //   thread = (channel vector cv = t & 7, strip = t >> 3); 32 strips of TWT outputs cover the TH x TW output tile.
-//   A block walks tiles blockIdx.x, +gridDim.x, ... so BN-stat / dW partials stay in registers until the end.
+//   A block walks tiles bpos.x, +gridDim.x, ... so BN-stat / dW partials stay in registers until the end.
 //   Software pipeline: the RAW loads of tile i+1 are issued before the LDS compute of tile i and only consumed at the top of
 //   the next iteration, so HBM requests stay in flight through the compute phase.
 #pragma once
@@ -58,9 +58,10 @@ __global__ void __launch_bounds__(256) dw_fwd_lds_kernel(DwGeom gm, ViewDev in, 
                                                          float* __restrict__ stats) {
     using T = LTile<S>;
     extern __shared__ float4 lds[];                      // [IH*IW][LPS]
+    const BlockPos bpos = xcd_block_pos();   // (tile slot, channel group), neighbouring slots on the same XCD / L2
     const int t = threadIdx.x, cv = t & 7, strip = t >> 3;
     const int srow = strip / T::SPR, scol = (strip % T::SPR) * T::TWT;
-    const int c0 = blockIdx.y * (LCV * 4) + cv * 4;
+    const int c0 = bpos.y * (LCV * 4) + cv * 4;
     const bool cok = c0 < gm.c;
     const int cs = cok ? c0 : 0;                         // safe channel offset for clamped loads
     float4 wk[9];
@@ -89,8 +90,8 @@ __global__ void __launch_bounds__(256) dw_fwd_lds_kernel(DwGeom gm, ViewDev in, 
             okmask |= (ok ? 1u : 0u) << k;
         }
     };
-    if ((long long)blockIdx.x < ntiles) fetch(blockIdx.x);
-    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    if ((long long)bpos.x < ntiles) fetch(bpos.x);
+    for (long long tile = bpos.x; tile < ntiles; tile += gridDim.x) {
         const TilePos tp = tile_pos(tile, tiles_w, tiles_h, T::TH);
         __syncthreads();
 #pragma unroll
@@ -131,7 +132,7 @@ __global__ void __launch_bounds__(256) dw_fwd_lds_kernel(DwGeom gm, ViewDev in, 
         const float4 a = reduce_strips(ssum, lds, t);
         const float4 b = reduce_strips(ssq, lds, t);
         if (t < LCV && cok) {
-            float* row = stats + (long long)blockIdx.x * 2 * gm.c;
+            float* row = stats + (long long)bpos.x * 2 * gm.c;
             st4(row + c0, a);
             st4(row + gm.c + c0, b);
         }
@@ -151,9 +152,10 @@ __global__ void __launch_bounds__(256) dw_bwd_lds_kernel(DwGeom gm, ViewDev in, 
     float4* td = ta + T::IH * T::IW * LPS;               // [DH*DW][LPS] dy
     float4* cw = td + T::DH * DW * LPS;                  // [9][LCV] filter taps, then [6][LCV] coefficients
     float4* cc = cw + 9 * LCV;
+    const BlockPos bpos = xcd_block_pos();   // (tile slot, channel group), neighbouring slots on the same XCD / L2
     const int t = threadIdx.x, cv = t & 7, strip = t >> 3;
     const int srow = strip / T::SPR, scol = (strip % T::SPR) * T::TWT;
-    const int c0 = blockIdx.y * (LCV * 4) + cv * 4;
+    const int c0 = bpos.y * (LCV * 4) + cv * 4;
     const bool cok = c0 < gm.c;
     const int cs = cok ? c0 : 0;
     const bool gaff = dy.scale != nullptr;
@@ -203,8 +205,8 @@ __global__ void __launch_bounds__(256) dw_bwd_lds_kernel(DwGeom gm, ViewDev in, 
             okd |= (ok ? 1u : 0u) << k;
         }
     };
-    if ((long long)blockIdx.x < ntiles) fetch(blockIdx.x);
-    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    if ((long long)bpos.x < ntiles) fetch(bpos.x);
+    for (long long tile = bpos.x; tile < ntiles; tile += gridDim.x) {
         const TilePos tp = tile_pos(tile, tiles_w, tiles_h, T::TH);
         __syncthreads();
         {
@@ -275,7 +277,7 @@ __global__ void __launch_bounds__(256) dw_bwd_lds_kernel(DwGeom gm, ViewDev in, 
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
         const float4 v = reduce_strips(dwacc[k], lds, t);
-        if (t < LCV && cok) st4(dwpart + ((long long)blockIdx.x * 9 + k) * gm.c + c0, v);
+        if (t < LCV && cok) st4(dwpart + ((long long)bpos.x * 9 + k) * gm.c + c0, v);
     }
 }
 
@@ -295,6 +297,7 @@ LdsLaunch lds_launch(const DwGeom& g) {
     if (gx * cgroups > 4096) gx = 4096 / cgroups < 64 ? 64 : 4096 / cgroups;
     if (gx > tiles) gx = tiles;
     if (gx < 1) gx = 1;
+    gx = (gx + 7) & ~7LL;   // multiple of 8 for the XCD remap (surplus blocks find no tile and write zero partial rows)
     l.grid = dim3((unsigned)gx, cgroups, 1);
     l.lds_fwd = (size_t)T::IH * T::IW * LPS * sizeof(float4);
     l.lds_bwd = l.lds_fwd + (size_t)(T::DH * T::DW * LPS + 15 * LCV) * sizeof(float4);

@@ -1,0 +1,216 @@
+// Column-marching depthwise 3x3 backward (stride 1, dilation 1) -- included by dwconv.hip after its helper definitions.
+//
+// Why a third shape: the register-window and LDS-tiled backward kernels carry a float4 channel vector per thread and end up
+// at 256 VGPRs (+AGPR spills), i.e. 1-2 waves per SIMD; with so little in flight they sit at 1.4-2.8 TB/s although neither
+// HBM (FETCH_SIZE == algorithmic after the XCD remap) nor the L1/TA path is saturated.  Here a thread owns ONE channel of a
+// 4-column output strip and marches down the rows of a row chunk with a rolling 3-row window of dy in registers:
+//   * every dy / x row is loaded once per thread (horizontal halo 6/4, shared with the neighbouring strip through L1);
+//   * ~90 VGPRs -> 4+ waves per SIMD, and the next row's 18 loads are issued before the current row's arithmetic;
+//   * lanes run along channels (then strips), so a wave still reads whole contiguous NHWC pixel segments;
+//   * the per-channel dW taps -- and, fused, the BatchNorm-backward sums of the layer feeding this one -- stay in
+//     registers for the whole march and leave as one partial row per block (deterministic two-level reduction).
+// BN fusion: dx is the gradient w.r.t. the ACTIVATED input a = act(s*x + t); the producer's BatchNorm backward needs
+// sum(mask*dx) and sum(mask*dx*xhat) over exactly the elements this kernel writes, and x is already in registers.
+#pragma once
+
+namespace {
+
+constexpr int MTW = 4;   // output columns per thread
+
+struct MarchGeom {
+    int n, h, w, c;
+    int rows;      // rows per chunk
+    int chunks;    // row chunks per image
+    int wstrips;   // ceil(w / MTW)
+    int cb;        // channels per block (<= 256)
+    int spb;       // strips per block
+    int sblocks;   // spatial blocks = n * chunks * ceil(wstrips / spb)
+    int sgroups;   // ceil(wstrips / spb)
+};
+
+template <bool BNFUSE>
+__global__ void __launch_bounds__(256) dw_bwd_march_kernel(MarchGeom gm, ViewDev in, const float* __restrict__ wgt, GViewDev dy,
+                                                            float* __restrict__ dx, float* __restrict__ dwpart, int accumulate,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            float* __restrict__ bnpart) {
+    extern __shared__ float mred[];   // [11][blockDim.x]
+    const BlockPos bpos = xcd_block_pos();
+    const int t = threadIdx.x;
+    const int sp = t / gm.cb, cl = t - sp * gm.cb;
+    const int ch = bpos.y * gm.cb + cl;
+    // spatial block -> (image, row chunk, strip group)
+    int sb = bpos.x;
+    const int sg = sb % gm.sgroups; sb /= gm.sgroups;
+    const int rc = sb % gm.chunks;
+    const int img = sb / gm.chunks;
+    const int ws = sg * gm.spb + sp;
+    const bool active = sp < gm.spb && ch < gm.c && ws < gm.wstrips && bpos.x < gm.sblocks;
+    const int chs = ch < gm.c ? ch : 0;   // safe channel for clamped addresses
+
+    const bool iaff = in.scale != nullptr, gaff = dy.scale != nullptr;
+    if (!gaff) { dy.y = dy.g; dy.act = SSDSEG_ACT_NONE; }   // identity gradient view, branch-free form (see common.h)
+    const float ilo = act_lo(in.act), ihi = act_hi(in.act);
+    const float glo = act_lo(dy.act), ghi = act_hi(dy.act);
+    const float is = iaff ? in.scale[chs] : 1.f, it = iaff ? in.shift[chs] : 0.f;
+    const float gs = gaff ? dy.scale[chs] : 1.f, gt = gaff ? dy.shift[chs] : 0.f;
+    const float gk1 = gaff ? dy.k1[chs] : 0.f, gk0 = gaff ? dy.k0[chs] : 0.f;
+    float mu = 0.f, istd = 0.f;
+    if (BNFUSE) { mu = mean[chs]; istd = invstd[chs]; }
+    float wk[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wk[k] = wgt[(long long)k * gm.c + chs];
+
+    float dwacc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dwacc[k] = 0.f;
+    float bsum = 0.f, bxh = 0.f;
+
+    if (active) {
+        const int w0 = ws * MTW;
+        const int r0 = rc * gm.rows;
+        const int r1 = r0 + gm.rows < gm.h ? r0 + gm.rows : gm.h;
+        // 32-bit element offsets from the (uniform) tensor bases: the launcher guarantees n*h*w*c < 2^31
+        const unsigned ibase = (unsigned)img * gm.h * gm.w * gm.c + ch;   // element (row, col) at ibase + (row*w + col)*c
+        const unsigned rstride = (unsigned)gm.w * gm.c;
+        bool cok[MTW + 2];
+        unsigned coff[MTW + 2];
+#pragma unroll
+        for (int a = 0; a < MTW + 2; ++a) {
+            const int col = w0 - 1 + a;
+            cok[a] = col >= 0 && col < gm.w;
+            coff[a] = (cok[a] ? col : 0) * gm.c;
+        }
+        auto load_dy_raw = [&](int row, float (&g)[MTW + 2], float (&y)[MTW + 2]) {
+            const bool rok = row >= 0 && row < gm.h;
+            const unsigned rb = ibase + (unsigned)(rok ? row : 0) * rstride;
+#pragma unroll
+            for (int a = 0; a < MTW + 2; ++a) {
+                g[a] = dy.g[rb + coff[a]];
+                y[a] = dy.y[rb + coff[a]];
+            }
+        };
+        auto make_dy = [&](int row, const float (&g)[MTW + 2], const float (&y)[MTW + 2], float (&d)[MTW + 2]) {
+            const bool rok = row >= 0 && row < gm.h;
+#pragma unroll
+            for (int a = 0; a < MTW + 2; ++a) {
+                const float z = fmaf(gs, y[a], gt);
+                const float m = (z > glo && z < ghi) ? gs : 0.f;
+                const float v = fmaf(m, g[a], fmaf(gk1, y[a], gk0));
+                d[a] = (rok && cok[a]) ? v : 0.f;
+            }
+        };
+        float dm[MTW + 2], d0[MTW + 2], dp[MTW + 2];
+        float sgr[MTW + 2], syr[MTW + 2], sxr[MTW + 2];   // staged raw loads of the next step
+        {
+            float g[MTW + 2], y[MTW + 2];
+            load_dy_raw(r0 - 1, g, y);
+            make_dy(r0 - 1, g, y, dm);
+            load_dy_raw(r0, g, y);
+            make_dy(r0, g, y, d0);
+        }
+        load_dy_raw(r0 + 1, sgr, syr);
+#pragma unroll
+        for (int a = 0; a < MTW + 2; ++a) sxr[a] = in.x[ibase + (unsigned)r0 * rstride + coff[a]];
+
+        for (int i = r0; i < r1; ++i) {
+            float xr[MTW + 2], xa[MTW + 2];
+            make_dy(i + 1, sgr, syr, dp);
+#pragma unroll
+            for (int a = 0; a < MTW + 2; ++a) {
+                xr[a] = sxr[a];
+                const float z = fminf(fmaxf(fmaf(is, xr[a], it), ilo), ihi);
+                xa[a] = cok[a] ? z : 0.f;
+            }
+            if (i + 1 < r1) {   // next step's loads go out before this step's arithmetic
+                load_dy_raw(i + 2, sgr, syr);
+                const unsigned rb = ibase + (unsigned)(i + 1) * rstride;
+#pragma unroll
+                for (int a = 0; a < MTW + 2; ++a) sxr[a] = in.x[rb + coff[a]];
+            }
+            // ---- dx[i][w0 + j] = sum_{kh,kw} dy[i - kh + 1][w0 + j - kw + 1] * w[kh][kw]
+            const unsigned ob = ibase + (unsigned)i * rstride;
+#pragma unroll
+            for (int j = 0; j < MTW; ++j) {
+                float acc = 0.f;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    acc = fmaf(dp[j - kw + 2], wk[0 * 3 + kw], acc);
+                    acc = fmaf(d0[j - kw + 2], wk[1 * 3 + kw], acc);
+                    acc = fmaf(dm[j - kw + 2], wk[2 * 3 + kw], acc);
+                }
+                if (cok[j + 1]) {
+                    if (dx != nullptr) {
+                        float* p = dx + (ob + coff[j + 1]);
+                        if (accumulate) acc += *p;
+                        *p = acc;
+                    }
+                    if (BNFUSE) {
+                        const float mg = (xa[j + 1] > ilo && xa[j + 1] < ihi) ? acc : 0.f;
+                        bsum += mg;
+                        bxh = fmaf(mg, (xr[j + 1] - mu) * istd, bxh);
+                    }
+                }
+            }
+            // ---- dW[kh][kw] += sum_j a[i][w0 + j + kw - 1] * dy[i - kh + 1][w0 + j]
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+                for (int j = 0; j < MTW; ++j) {
+                    dwacc[0 * 3 + kw] = fmaf(xa[j + kw], dp[j + 1], dwacc[0 * 3 + kw]);
+                    dwacc[1 * 3 + kw] = fmaf(xa[j + kw], d0[j + 1], dwacc[1 * 3 + kw]);
+                    dwacc[2 * 3 + kw] = fmaf(xa[j + kw], dm[j + 1], dwacc[2 * 3 + kw]);
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < MTW + 2; ++a) { dm[a] = d0[a]; d0[a] = dp[a]; }
+        }
+    }
+
+    // ---- block partials: sum over the block's strips (fixed order), one row per spatial block
+    const int nth = blockDim.x;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) mred[k * nth + t] = dwacc[k];
+    if (BNFUSE) { mred[9 * nth + t] = bsum; mred[10 * nth + t] = bxh; }
+    __syncthreads();
+    if (sp == 0 && ch < gm.c) {
+        const int nv = BNFUSE ? 11 : 9;
+        for (int k = 0; k < nv; ++k) {
+            float s = 0.f;
+            for (int q = 0; q < gm.spb; ++q) s += mred[k * nth + q * gm.cb + cl];
+            if (k < 9) dwpart[((long long)bpos.x * 9 + k) * gm.c + ch] = s;
+            else bnpart[((long long)bpos.x * 2 + (k - 9)) * gm.c + ch] = s;
+        }
+    }
+}
+
+struct MarchLaunch {
+    dim3 grid, block;
+    size_t lds;
+};
+
+// geometry for an n x h x w x c tensor: channel chunks of <= 256, as many strips per block as fit in 256 threads, row chunks
+// sized so that the launch has >= ~4096 waves (16 per CU) where the layer is big enough
+inline MarchLaunch march_geometry(int n, int h, int w, int c, MarchGeom* g) {
+    g->n = n; g->h = h; g->w = w; g->c = c;
+    g->wstrips = cdiv(w, MTW);
+    const int cchunks = cdiv(c, 256);
+    g->cb = cdiv(c, cchunks);
+    g->spb = 256 / g->cb;
+    if (g->spb < 1) g->spb = 1;
+    if (g->spb > g->wstrips) g->spb = g->wstrips;
+    g->sgroups = cdiv(g->wstrips, g->spb);
+    const int threads = ((g->cb * g->spb + 63) / 64) * 64;
+    const long long waves_per_chunkrow = (long long)n * g->sgroups * cchunks * (threads / 64);
+    int rows = h;
+    while (rows > 8 && waves_per_chunkrow * cdiv(h, rows) < 4096) rows = (rows + 1) / 2;
+    g->rows = rows;
+    g->chunks = cdiv(h, rows);
+    g->sblocks = n * g->chunks * g->sgroups;
+    MarchLaunch l;
+    l.grid = dim3((unsigned)((g->sblocks + 7) & ~7), cchunks, 1);   // multiple of 8 for the XCD remap
+    l.block = dim3(threads, 1, 1);
+    l.lds = (size_t)11 * threads * sizeof(float);
+    return l;
+}
+
+}  // namespace

@@ -98,6 +98,7 @@ class BNRec:
         self.shift = shift if shift is not None else ctx.empty(c)
         self.mean, self.invstd, self.k1, self.k0 = ctx.empty(c), ctx.empty(c), ctx.empty(c), ctx.empty(c)
         self.act = ACT_NONE
+        self.bwd_done = False     # this step's backward reduction was already produced by a fused consumer kernel
 
 
 class Val:
@@ -179,9 +180,18 @@ class DwOp(Op):
         self.e.ctx.call("ssdseg_dwconv_fwd", self.inp.view(), self.w, self.out.buf, s.n, s.h, s.w, s.c, self.stride, self.dilation,
                         self.out.stats)
 
+    fuse_input_bn = False   # set by the lowering when this conv is the only consumer of a BatchNorm(+ReLU) output
+
     def bwd(self):
         s = self.inp.store
         dx, acc = (s.grad_slot() if s.need_grad else (None, 0))
+        b = self.inp.bn
+        if self.fuse_input_bn and b is not None and dx is not None and acc == 0:
+            # the kernel that writes dx also reduces the producer BN's (dgamma, dbeta, k1, k0): no second pass over the 6x-wide tensor
+            self.e.ctx.call("ssdseg_dwconv_bwd_bn", self.inp.view(), self.w, self.out_val.gview(), dx, self.dw, s.n, s.h, s.w, s.c,
+                            self.stride, self.dilation, b.mean, b.invstd, b.dgamma, b.dbeta, b.k1, b.k0)
+            b.bwd_done = True
+            return
         self.e.ctx.call("ssdseg_dwconv_bwd", self.inp.view(), self.w, self.out_val.gview(), dx, self.dw, s.n, s.h, s.w, s.c, self.stride,
                         self.dilation, acc)
 
@@ -253,6 +263,9 @@ class BnOp(Op):
 
     def bwd(self):
         r, s = self.rec, self.store
+        if r.bwd_done:            # reduced by the consumer's backward kernel (DwOp.bwd)
+            r.bwd_done = False
+            return
         self.e.ctx.call("ssdseg_bn_bwd_reduce", s.grad, s.ld, s.buf, s.ld, s.m, r.c, r.scale, r.shift, r.mean, r.invstd, r.act, r.dgamma,
                         r.dbeta, r.k1, r.k0)
 
@@ -653,6 +666,9 @@ class Engine:
             assert layer.strides[0] == layer.strides[1] and layer.dilation_rate[0] == layer.dilation_rate[1]
             st = self._out_store(layer, out_t.shape)
             op = self._emit(DwOp(self, layer, "depthwise_kernel", self._dense(ins[0], layer.name), st, layer.strides[0], layer.dilation_rate[0]))
+            src = layer.inbound[0]
+            op.fuse_input_bn = (op.inp is ins[0] and ins[0].bn is not None and len(self.cons.get(id(src), [])) == 1
+                                and id(src) not in {id(t) for t in self.model.outputs})
             op.out_val = Val(st)
             setv(op.out_val)
             st.producer = op

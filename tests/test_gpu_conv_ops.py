@@ -96,6 +96,25 @@ def test_dwconv_fwd_bwd(ctx, rng, n, h, w, c, s, d, act):
     dx_ref2, dw_ref2 = O.dwconv_bwd(a, wgt, g, s, d)
     assert rel_err(ddx.download(), dx_ref2) < 2e-5
     assert rel_err(ddw.download(), dw_ref2) < 1e-4
+    # fused: the same backward + the BatchNorm-backward reduction of the layer feeding this conv (x is that BN's raw input)
+    mean = x.mean(axis=(0, 1, 2), dtype=np.float64).astype(np.float32)
+    invstd = (1.0 / np.sqrt(x.var(axis=(0, 1, 2), dtype=np.float64) + 1e-3)).astype(np.float32)
+    outs = [ctx.empty(c) for _ in range(4)]
+    ctx.call("ssdseg_dwconv_bwd_bn", H.view(dx_, dsc, dsh, act), dw_, gv, ddx, ddw, n, h, w, c, s, d, ctx.array(mean), ctx.array(invstd), *outs)
+    assert rel_err(ddx.download(), dx_ref) < 2e-5
+    assert rel_err(ddw.download(), dw_ref) < 1e-4
+    z = x.astype(np.float64) * sc + sh
+    mg = dx_ref.astype(np.float64) * O.act_mask(z, act)
+    xhat = (x.astype(np.float64) - mean) * invstd
+    dbeta, dgamma = mg.sum(axis=(0, 1, 2)), (mg * xhat).sum(axis=(0, 1, 2))
+    cnt = float(n * h * w)
+    tol = 1e-4 * max(np.abs(dgamma).max(), np.abs(dbeta).max(), 1e-6)
+    assert np.abs(outs[0].download() - dgamma).max() < tol
+    assert np.abs(outs[1].download() - dbeta).max() < tol
+    k1_ref = -sc.astype(np.float64) * dgamma * invstd / cnt
+    k0_ref = sc.astype(np.float64) * (dgamma * invstd * mean - dbeta) / cnt
+    assert np.abs(outs[2].download() - k1_ref).max() < 1e-4 * max(np.abs(k1_ref).max(), 1e-9)
+    assert np.abs(outs[3].download() - k0_ref).max() < 1e-4 * max(np.abs(k0_ref).max(), 1e-9)
 
 
 PW_CASES = [
