@@ -380,7 +380,7 @@ int dw_bwd_impl(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, const ss
     const double cost_bytes = 4.0 * (2.0 * n * h * wdt * c + (double)n * g.ho * g.wo * c + 18.0 * c);
     const double cost_flops = 36.0 * n * g.ho * g.wo * c;
     const int choice = dw_bwd_choice();
-    const bool march_ok = dilation == 1 && stride == 1 && (long long)n * h * wdt * c < (1LL << 31);
+    const bool march_ok = dilation == 1 && stride == 1 && (long long)n * h * wdt * c < (1LL << 30);   // 32-bit byte offsets
     if (bn_done) *bn_done = false;
     if (march_ok && (choice == 0 || choice == 1)) {
         MarchGeom mg;
@@ -392,13 +392,15 @@ int dw_bwd_impl(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, const ss
         if (rc) return rc;
         float* part = (float*)ws;
         float* bnpart = part + (size_t)nparts * 9 * c;
-        if (fuse) {
-            SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_bwd_march_kernel<true>), ml.grid, ml.block, ml.lds, mg, v, w, gv, dx, part, accumulate,
-                          bn->mean, bn->invstd, bnpart);
-        } else {
-            SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_bwd_march_kernel<false>), ml.grid, ml.block, ml.lds, mg, v, w, gv, dx, part, accumulate,
-                          (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
-        }
+        const bool wfull = wdt % MTW == 0;
+#define DW_BWD_MARCH(BN_, WF_)                                                                                                              \
+    SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_bwd_march_kernel<BN_, WF_>), ml.grid, ml.block, ml.lds, mg, v, w, gv, dx, part, accumulate, \
+                  fuse ? bn->mean : (const float*)nullptr, fuse ? bn->invstd : (const float*)nullptr, fuse ? bnpart : (float*)nullptr)
+        if (fuse && wfull) DW_BWD_MARCH(true, true);
+        else if (fuse) DW_BWD_MARCH(true, false);
+        else if (wfull) DW_BWD_MARCH(false, true);
+        else DW_BWD_MARCH(false, false);
+#undef DW_BWD_MARCH
         SSDSEG_LAUNCH_CHECK();
         rc = ssdseg_colsum(ctx, part, nparts, 9LL * c, dw);
         if (rc || !fuse) return rc;

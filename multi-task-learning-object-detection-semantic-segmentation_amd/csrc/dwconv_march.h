@@ -5,8 +5,10 @@
 // HBM (FETCH_SIZE == algorithmic after the XCD remap) nor the L1/TA path is saturated.  Here a thread owns ONE channel of a
 // 4-column output strip and marches down the rows of a row chunk with a rolling 3-row window of dy in registers:
 //   * every dy / x row is loaded once per thread (horizontal halo 6/4, shared with the neighbouring strip through L1);
-//   * ~90 VGPRs -> 4+ waves per SIMD, and the next row's 18 loads are issued before the current row's arithmetic;
-//   * lanes run along channels (then strips), so a wave still reads whole contiguous NHWC pixel segments;
+//   * ~120 VGPRs -> 4 waves per SIMD; the next row's 18 loads are issued before the current row's arithmetic into the OTHER
+//     of two staging register sets (the row loop is unrolled by two), so no s_waitcnt sits between issue and the next step;
+//   * lanes run along channels (then strips), so a wave still reads whole contiguous NHWC pixel segments; addresses are
+//     one uniform base + a 32-bit byte offset per lane (saddr form: one v_add per load);
 //   * the per-channel dW taps -- and, fused, the BatchNorm-backward sums of the layer feeding this one -- stay in
 //     registers for the whole march and leave as one partial row per block (deterministic two-level reduction).
 // BN fusion: dx is the gradient w.r.t. the ACTIVATED input a = act(s*x + t); the producer's BatchNorm backward needs
@@ -15,7 +17,8 @@
 
 namespace {
 
-constexpr int MTW = 4;   // output columns per thread
+constexpr int MTW = 4;        // output columns per thread
+constexpr int MWC = MTW + 2;  // window columns
 
 struct MarchGeom {
     int n, h, w, c;
@@ -28,7 +31,16 @@ struct MarchGeom {
     int sgroups;   // ceil(wstrips / spb)
 };
 
-template <bool BNFUSE>
+__device__ __forceinline__ float ldg_b(const float* base, unsigned byte_off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+struct MarchStage {   // raw loads of one step: dy row i+1 (g, y) and x row i
+    float g[MWC], y[MWC], x[MWC];
+};
+
+// WFULL: w % MTW == 0, the four owned columns always exist (only the two halo columns are conditional)
+template <bool BNFUSE, bool WFULL>
 __global__ void __launch_bounds__(256) dw_bwd_march_kernel(MarchGeom gm, ViewDev in, const float* __restrict__ wgt, GViewDev dy,
                                                             float* __restrict__ dx, float* __restrict__ dwpart, int accumulate,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -58,7 +70,7 @@ __global__ void __launch_bounds__(256) dw_bwd_march_kernel(MarchGeom gm, ViewDev
     if (BNFUSE) { mu = mean[chs]; istd = invstd[chs]; }
     float wk[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) wk[k] = wgt[(long long)k * gm.c + chs];
+    for (int k = 0; k < 9; ++k) wk[k] = wgt[k * gm.c + chs];
 
     float dwacc[9];
 #pragma unroll
@@ -69,64 +81,59 @@ __global__ void __launch_bounds__(256) dw_bwd_march_kernel(MarchGeom gm, ViewDev
         const int w0 = ws * MTW;
         const int r0 = rc * gm.rows;
         const int r1 = r0 + gm.rows < gm.h ? r0 + gm.rows : gm.h;
-        // 32-bit element offsets from the (uniform) tensor bases: the launcher guarantees n*h*w*c < 2^31
-        const unsigned ibase = (unsigned)img * gm.h * gm.w * gm.c + ch;   // element (row, col) at ibase + (row*w + col)*c
-        const unsigned rstride = (unsigned)gm.w * gm.c;
-        bool cok[MTW + 2];
-        unsigned coff[MTW + 2];
+        // 32-bit BYTE offsets from the (uniform) tensor bases: the launcher guarantees n*h*w*c*4 < 2^32
+        const unsigned ibase = (((unsigned)img * gm.h * gm.w) * gm.c + ch) * 4u;   // element (row, col) at ibase + (row*w + col)*c*4
+        const unsigned rstride = (unsigned)gm.w * gm.c * 4u;
+        bool cok[MWC];
+        unsigned coff[MWC];
 #pragma unroll
-        for (int a = 0; a < MTW + 2; ++a) {
+        for (int a = 0; a < MWC; ++a) {
             const int col = w0 - 1 + a;
-            cok[a] = col >= 0 && col < gm.w;
-            coff[a] = (cok[a] ? col : 0) * gm.c;
+            cok[a] = (WFULL && a >= 1 && a <= MTW) ? true : (col >= 0 && col < gm.w);
+            coff[a] = (unsigned)(cok[a] ? col : 0) * gm.c * 4u;
         }
-        auto load_dy_raw = [&](int row, float (&g)[MTW + 2], float (&y)[MTW + 2]) {
-            const bool rok = row >= 0 && row < gm.h;
-            const unsigned rb = ibase + (unsigned)(rok ? row : 0) * rstride;
+        // issue the raw loads of one step: dy row `drow` (clamped into the image; masked later) and x row `xrow` (always valid)
+        auto issue = [&](int drow, int xrow, MarchStage& s) {
+            const int dclamp = drow < 0 ? 0 : (drow >= gm.h ? gm.h - 1 : drow);
+            const unsigned db = ibase + (unsigned)dclamp * rstride, xb = ibase + (unsigned)xrow * rstride;
 #pragma unroll
-            for (int a = 0; a < MTW + 2; ++a) {
-                g[a] = dy.g[rb + coff[a]];
-                y[a] = dy.y[rb + coff[a]];
+            for (int a = 0; a < MWC; ++a) {
+                s.g[a] = ldg_b(dy.g, db + coff[a]);
+                s.y[a] = ldg_b(dy.y, db + coff[a]);
+                s.x[a] = ldg_b(in.x, xb + coff[a]);
             }
         };
-        auto make_dy = [&](int row, const float (&g)[MTW + 2], const float (&y)[MTW + 2], float (&d)[MTW + 2]) {
+        auto make_dy = [&](int row, const float (&g)[MWC], const float (&y)[MWC], float (&d)[MWC]) {
             const bool rok = row >= 0 && row < gm.h;
 #pragma unroll
-            for (int a = 0; a < MTW + 2; ++a) {
+            for (int a = 0; a < MWC; ++a) {
                 const float z = fmaf(gs, y[a], gt);
                 const float m = (z > glo && z < ghi) ? gs : 0.f;
                 const float v = fmaf(m, g[a], fmaf(gk1, y[a], gk0));
                 d[a] = (rok && cok[a]) ? v : 0.f;
             }
         };
-        float dm[MTW + 2], d0[MTW + 2], dp[MTW + 2];
-        float sgr[MTW + 2], syr[MTW + 2], sxr[MTW + 2];   // staged raw loads of the next step
+        float dm[MWC], d0[MWC], dp[MWC];
         {
-            float g[MTW + 2], y[MTW + 2];
-            load_dy_raw(r0 - 1, g, y);
-            make_dy(r0 - 1, g, y, dm);
-            load_dy_raw(r0, g, y);
-            make_dy(r0, g, y, d0);
+            MarchStage p;
+            issue(r0 - 1, r0, p);
+            make_dy(r0 - 1, p.g, p.y, dm);
+            issue(r0, r0, p);
+            make_dy(r0, p.g, p.y, d0);
         }
-        load_dy_raw(r0 + 1, sgr, syr);
+        // one row: consume `cur` (dy row i+1, x row i), refill `nxt` for row i+1
+        auto step = [&](int i, MarchStage& cur, MarchStage& nxt) {
+            float xa[MWC];
+            make_dy(i + 1, cur.g, cur.y, dp);
 #pragma unroll
-        for (int a = 0; a < MTW + 2; ++a) sxr[a] = in.x[ibase + (unsigned)r0 * rstride + coff[a]];
-
-        for (int i = r0; i < r1; ++i) {
-            float xr[MTW + 2], xa[MTW + 2];
-            make_dy(i + 1, sgr, syr, dp);
-#pragma unroll
-            for (int a = 0; a < MTW + 2; ++a) {
-                xr[a] = sxr[a];
-                const float z = fminf(fmaxf(fmaf(is, xr[a], it), ilo), ihi);
+            for (int a = 0; a < MWC; ++a) {
+                const float z = fminf(fmaxf(fmaf(is, cur.x[a], it), ilo), ihi);
                 xa[a] = cok[a] ? z : 0.f;
             }
-            if (i + 1 < r1) {   // next step's loads go out before this step's arithmetic
-                load_dy_raw(i + 2, sgr, syr);
-                const unsigned rb = ibase + (unsigned)(i + 1) * rstride;
-#pragma unroll
-                for (int a = 0; a < MTW + 2; ++a) sxr[a] = in.x[rb + coff[a]];
-            }
+            // next step's loads go out before this step's arithmetic.  Unconditional (the last step re-reads row r1-1 into
+            // registers nobody consumes): a branch here makes the compiler's s_waitcnt placement merge the "no new loads"
+            // path and wait for the new loads immediately (vmcnt(1) instead of vmcnt(18)), i.e. no overlap at all
+            issue(i + 2, i + 1 < r1 ? i + 1 : r1 - 1, nxt);
             // ---- dx[i][w0 + j] = sum_{kh,kw} dy[i - kh + 1][w0 + j - kw + 1] * w[kh][kw]
             const unsigned ob = ibase + (unsigned)i * rstride;
 #pragma unroll
@@ -138,16 +145,16 @@ __global__ void __launch_bounds__(256) dw_bwd_march_kernel(MarchGeom gm, ViewDev
                     acc = fmaf(d0[j - kw + 2], wk[1 * 3 + kw], acc);
                     acc = fmaf(dm[j - kw + 2], wk[2 * 3 + kw], acc);
                 }
-                if (cok[j + 1]) {
+                if (WFULL || cok[j + 1]) {
                     if (dx != nullptr) {
-                        float* p = dx + (ob + coff[j + 1]);
+                        float* p = reinterpret_cast<float*>(reinterpret_cast<char*>(dx) + (ob + coff[j + 1]));
                         if (accumulate) acc += *p;
                         *p = acc;
                     }
                     if (BNFUSE) {
                         const float mg = (xa[j + 1] > ilo && xa[j + 1] < ihi) ? acc : 0.f;
                         bsum += mg;
-                        bxh = fmaf(mg, (xr[j + 1] - mu) * istd, bxh);
+                        bxh = fmaf(mg, (cur.x[j + 1] - mu) * istd, bxh);
                     }
                 }
             }
@@ -162,8 +169,16 @@ __global__ void __launch_bounds__(256) dw_bwd_march_kernel(MarchGeom gm, ViewDev
                 }
             }
 #pragma unroll
-            for (int a = 0; a < MTW + 2; ++a) { dm[a] = d0[a]; d0[a] = dp[a]; }
+            for (int a = 0; a < MWC; ++a) { dm[a] = d0[a]; d0[a] = dp[a]; }
+        };
+        MarchStage sa, sb2;
+        issue(r0 + 1, r0, sa);
+        int i = r0;
+        for (; i + 1 < r1; i += 2) {   // straight-line pairs: both staging sets keep their roles across the back edge
+            step(i, sa, sb2);
+            step(i + 1, sb2, sa);
         }
+        if (i < r1) step(i, sa, sb2);
     }
 
     // ---- block partials: sum over the block's strips (fixed order), one row per spatial block
