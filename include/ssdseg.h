@@ -158,6 +158,11 @@ int ssdseg_pwconv_bwd_data(ssdseg_ctx* ctx, const ssdseg_gview* dy, int ldy, con
 /* dw[k][n] = sum_m in[m][k] * dy[m][n] */
 int ssdseg_pwconv_bwd_weight(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssdseg_gview* dy, int ldy,
                              float* dw, int m, int k, int n);
+/* Both of the above in one call.  For k <= 32 and n <= 192 (the MBConv expand convs, models.py:65 with 6x expansion) ONE
+ * kernel produces dx and dw from a single pass over the gradient view; other shapes run the two kernels above. */
+int ssdseg_pwconv_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssdseg_gview* dy, int ldy, const float* w,
+                      float* dx, int lddx, float* dw, int m, int k, int n, const float* residual, int ldr,
+                      int accumulate);
 
 /* ---------------------------------------------------------------- K6: dense 3x3 stride 1 SAME (implicit GEMM)
  * Conv2D 3x3 in the DeepLabV3+ decoder (blocks.py:117,127).  w: [3][3][cin][cout]. */

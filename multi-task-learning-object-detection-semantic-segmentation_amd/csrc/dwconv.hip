@@ -376,8 +376,9 @@ int dw_bwd_impl(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, const ss
     dw_geometry(n, h, wdt, c, stride, dilation, &g, &l);
     ViewDev v{in->x, in->scale, in->shift, in->act};
     GViewDev gv{dy->g, dy->y, dy->scale, dy->shift, dy->k1, dy->k0, dy->act};
-    // algorithmic traffic: read X, read dY, write dX, read W, write dW
-    const double cost_bytes = 4.0 * (2.0 * n * h * wdt * c + (double)n * g.ho * g.wo * c + 18.0 * c);
+    // algorithmic traffic: read X, read dY (a BatchNorm-backward gradient view is two tensors, g and y), write dX,
+    // read W, write dW
+    const double cost_bytes = 4.0 * (2.0 * n * h * wdt * c + (dy->scale != nullptr ? 2.0 : 1.0) * n * g.ho * g.wo * c + 18.0 * c);
     const double cost_flops = 36.0 * n * g.ho * g.wo * c;
     const int choice = dw_bwd_choice();
     const bool march_ok = dilation == 1 && stride == 1 && (long long)n * h * wdt * c < (1LL << 30);   // 32-bit byte offsets

@@ -15,6 +15,8 @@
 // The next tile's global loads are issued before the current tile's MFMAs (register prefetch).
 #include "common.h"
 
+#include <stdlib.h>
+
 int ssdseg_colsum(ssdseg_ctx* ctx, const float* part, int nparts, long long len, float* out);
 
 namespace {
@@ -50,6 +52,13 @@ struct RowAArgs {
     int stemH, stemW, stemPt, stemPl;
     float stemScale, stemOffset;
     const float* bias;
+    // fused backward (NT > 0, MODE 1): the layer's INPUT view x[I][J] (a = act(xs*x + xt)) and the per-block partial slabs of
+    // dW[J][R] = sum_m a[m][j] * dy[m][r]  ([gridDim.y][J][R]); the dy tile already sits in LDS for the dx product
+    const float* xw;
+    const float* xws;
+    const float* xwt;
+    int xwact, ldxw;
+    float* wpart;
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -57,9 +66,13 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 }
 
 // LD: how the streamed operand is addressed -- 0 plain row-major matrix, 1 dense 3x3 stride-1 gather, 2 stem gather
-template <int WN, int MODE, int LD>
+// NT > 0 (MODE 1, LD 0, WN 1, J <= 32, R <= 32*NT): fused backward of a pointwise conv with few input channels (the MBConv
+// expand convs): the same pass over (g, y) that yields dx = dy * W^T also accumulates dW = a^T * dy, one 32x32 tile per
+// 32-column chunk of dy, each wave over its own 32 rows -- so the 6x-wide gradient is read once instead of twice.
+template <int WN, int MODE, int LD, int NT = 0>
 __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
-    constexpr bool CONV = LD == 1, STEM = LD == 2;
+    constexpr bool CONV = LD == 1, STEM = LD == 2, FUSEW = NT > 0;
+    static_assert(!FUSEW || (MODE == 1 && LD == 0 && WN == 1), "fused dW only for plain backward-data with one column tile");
     constexpr int BN = 32 * WN;
     constexpr int BS = BN + 1;
     extern __shared__ float smem[];
@@ -175,6 +188,12 @@ __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
     float ssum[WN], ssq[WN];   // BN statistics of this block's rows, carried across its row tiles
 #pragma unroll
     for (int nt = 0; nt < WN; ++nt) ssum[nt] = ssq[nt] = 0.f;
+    f32x16 wacc[FUSEW ? NT : 1];   // FUSEW: this wave's partial of dW[j][32*kt + ..] over its rows, carried across row tiles
+#pragma unroll
+    for (int q = 0; q < (FUSEW ? NT : 1); ++q)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) wacc[q][e] = 0.f;
+    float xop[FUSEW ? 16 : 1];     // FUSEW: A operand a[m0 + 32*wave + 2s + hh][j = li] of the dW products, per row tile
 
     // a block walks row tiles blockIdx.y, blockIdx.y + gridDim.y, ... so the number of BN partial rows stays small
     for (int mt = blockIdx.y; mt < mtiles; mt += gridDim.y) {
@@ -196,12 +215,31 @@ __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
 
+    if (FUSEW) {
+        const float xlo = act_lo(p.xwact), xhi = act_hi(p.xwact);
+        const bool jok = li < p.J;
+        const float xs = (p.xws != nullptr && jok) ? p.xws[li] : 1.f, xt = (p.xws != nullptr && jok) ? p.xwt[li] : 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int m = m0 + wave * 32 + 2 * s + hh;
+            const bool ok = jok && m < p.I;
+            const float v = p.xw[ok ? (long long)m * p.ldxw + li : 0];
+            xop[s] = ok ? fminf(fmaxf(fmaf(xs, v, xt), xlo), xhi) : 0.f;
+        }
+    }
     load_tiles(0);
-    for (int kt = 0; kt < KT; ++kt) {
+    // one 32-deep reduction step; `wtile` = which dW accumulator this step feeds (a compile-time constant in the fused loop)
+    auto kstep = [&](int kt, f32x16& wtile) {
         __syncthreads();
         store_tiles();
         __syncthreads();
         if (kt + 1 < KT) load_tiles(kt + 1);
+        if (FUSEW) {
+            // dW tile kt: rows of the reduction = this wave's 32 tile rows, B operand dy[row][32*kt + li] straight from As
+            const float* dcol = As + (wave * 32 + hh) * AS + li;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) wtile = mfma32(xop[s], dcol[(2 * s) * AS], wtile);
+        }
         const float* arow = As + (wave * 32 + li) * AS + 4 * hh;
         const float* bcol = Bs + (4 * hh) * BS + li;
 #pragma unroll
@@ -217,6 +255,13 @@ __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
                 }
             }
         }
+    };
+    if (FUSEW) {
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+            if (kt < KT) kstep(kt, wacc[kt]);
+    } else {
+        for (int kt = 0; kt < KT; ++kt) kstep(kt, wacc[0]);
     }
 
     // ---------------- epilogue: C/D layout col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
@@ -248,6 +293,30 @@ __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
         }
     }
     }  // row-tile loop
+
+    if (FUSEW) {
+        // this block's dW partial slab [J][R]: sum the four waves' row-quarters tile by tile through LDS (fixed order)
+        float* red = smem;   // [3 waves][16][64]
+        float* slab = p.wpart + (long long)blockIdx.y * p.J * p.R;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            __syncthreads();
+            if (wave > 0) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) red[((wave - 1) * 16 + e) * 64 + lane] = wacc[kt][e];
+            }
+            __syncthreads();
+            if (wave == 0) {
+                const int n = kt * 32 + li;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float v = ((wacc[kt][e] + red[(0 * 16 + e) * 64 + lane]) + red[(1 * 16 + e) * 64 + lane]) + red[(2 * 16 + e) * 64 + lane];
+                    const int k = (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    if (k < p.J && n < p.R) slab[(long long)k * p.R + n] = v;
+                }
+            }
+        }
+    }
 
     if (MODE == 0 && p.stats != nullptr) {
         __syncthreads();
@@ -300,11 +369,14 @@ struct WGradArgs {
     float stemScale, stemOffset;
 };
 
-constexpr int RW = 16;  // reduction rows per wave per step
+// reduction rows per wave per step: 64 rows per block step when the waves split the rows 4- or 2-way, 32 when all four waves
+// sit along k (16-row steps left that shape with two barriers per 8 MFMAs: 2.5-3.2 TB/s of real traffic)
+constexpr int rw_of(int wr) { return wr == 4 ? 16 : 32; }
 
 // WI waves along the output rows (k), WR waves splitting the reduction rows (m); WI*WR == 4.
 template <int WI, int WR, int WN>
 __global__ void __launch_bounds__(256) gemm_wgrad_kernel(WGradArgs p) {
+    constexpr int RW = rw_of(WR);
     constexpr int BI = 32 * WI, BJ = 32 * WN, BRT = RW * WR;
     extern __shared__ float smem[];
     float* Xs = smem;              // [BRT][BI]
@@ -509,8 +581,10 @@ int launch_rowA(ssdseg_ctx* ctx, const RowAArgs& a) {
     size_t lds = (size_t)(BM * AS + BK * (32 * wn + 1)) * sizeof(float);
     size_t red = (size_t)(4 * 2 * 32 * wn) * sizeof(float);
     if (red > lds) lds = red;
-    // algorithmic: read the streamed operand and the weights once, write the output once
-    const double cost_bytes = 4.0 * ((double)a.I * a.R + (double)a.I * a.J + (double)a.R * a.J);
+    // algorithmic: read the streamed operand and the weights once, write the output once; a BatchNorm-backward gradient view
+    // is formed from TWO tensors (g and the raw forward output y), both of which have to be read
+    const double streamed = (MODE == 1 && a.cs != nullptr) ? 2.0 : 1.0;
+    const double cost_bytes = 4.0 * (streamed * a.I * a.R + (double)a.I * a.J + (double)a.R * a.J);
     const double cost_flops = 2.0 * a.I * a.R * a.J;
     char kbuf[64];
     snprintf(kbuf, sizeof(kbuf), "gemm_rowA_kernel<%d, %d, %d>", wn, MODE, LD);
@@ -528,11 +602,11 @@ int launch_rowA(ssdseg_ctx* ctx, const RowAArgs& a) {
 
 template <int WI, int WR>
 int launch_wgrad_wn(ssdseg_ctx* ctx, const WGradArgs& a, int wn, dim3 grid) {
-    size_t lds = (size_t)(RW * WR) * (32 * WI + 32 * wn) * sizeof(float);
+    size_t lds = (size_t)(rw_of(WR) * WR) * (32 * WI + 32 * wn) * sizeof(float);
     size_t red = (size_t)(WR - 1) * WI * wn * 16 * 64 * sizeof(float);
     if (red > lds) lds = red;
     const double share = 1.0 / ((double)grid.x * grid.y);   // every (k-tile, n-tile) block column re-reads its operands
-    const double cost_bytes = 4.0 * ((double)a.M * a.K + (double)a.M * a.N + (double)a.K * a.N);
+    const double cost_bytes = 4.0 * ((double)a.M * a.K + (a.gs != nullptr ? 2.0 : 1.0) * a.M * a.N + (double)a.K * a.N);
     const double cost_flops = 2.0 * a.M * a.K * a.N;
     (void)share;
     char kbuf[64];
@@ -554,7 +628,7 @@ int wgrad_run(ssdseg_ctx* ctx, WGradArgs a, float* dw) {
     const int m = a.M, k = a.K, n = a.N;
     const int wi = k <= 32 ? 1 : (k <= 64 ? 2 : 4);
     const int wr = 4 / wi;
-    const int brt = RW * wr;
+    const int brt = rw_of(wr) * wr;
     const int itiles = cdiv(k, 32 * wi);
     long long steps = ((long long)m + brt - 1) / brt;
     // split the reduction rows so that (a) the chip is full, (b) every block still does >= 4 steps and (c) the partial
@@ -562,7 +636,9 @@ int wgrad_run(ssdseg_ctx* ctx, WGradArgs a, float* dw) {
     long long max_splits = (steps + 3) / 4;
     const long long traffic_cap = (long long)((double)m * (k + n) / (2.0 * k * n));
     if (max_splits > traffic_cap) max_splits = traffic_cap < 1 ? 1 : traffic_cap;
-    const int wn = pick_wn(n, (long long)itiles * max_splits);
+    int wn = pick_wn(n, (long long)itiles * max_splits);
+    // the 4-way row-split shape stages 64 x (32*wn) of (g, y) per step: beyond 3 column tiles it needs > 256 VGPRs (1 wave/SIMD)
+    if (wi == 1 && wn > 3) wn = 3;
     const int jtiles = cdiv(n, 32 * wn);
     long long want = (4LL * ctx->num_cus + (long long)itiles * jtiles - 1) / ((long long)itiles * jtiles);
     long long splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
@@ -642,6 +718,74 @@ int ssdseg_pwconv_bwd_data(ssdseg_ctx* ctx, const ssdseg_gview* dy, int ldy, con
     a.residual = residual; a.ldr = ldr; a.accumulate = accumulate;
     a.I = m; a.R = n; a.J = k;
     return launch_rowA<1, 0>(ctx, a);
+}
+
+// dx and dW of a pointwise conv in ONE pass over the gradient (models.py:65-67 backward).  Shapes the fused kernel covers:
+// k <= 32 input channels, n <= 192 output channels (MobileNetV2 expand convs of blocks 1-6, where the 6x-wide gradient
+// is the whole cost); everything else runs the two separate kernels -- same results either way.
+int ssdseg_pwconv_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssdseg_gview* dy, int ldy, const float* w, float* dx,
+                      int lddx, float* dw, int m, int k, int n, const float* residual, int ldr, int accumulate) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(in != nullptr && in->x != nullptr && ((in->scale == nullptr) == (in->shift == nullptr)), 2);
+    SSDSEG_ARG(ldx >= k && ldx % 4 == 0, 3);
+    SSDSEG_ARG(dy != nullptr && dy->g != nullptr, 4);
+    SSDSEG_ARG(dy->scale == nullptr || (dy->y && dy->shift && dy->k1 && dy->k0), 4);
+    SSDSEG_ARG(ldy >= n && ldy % 4 == 0, 5);
+    SSDSEG_ARG(w != nullptr, 6);
+    SSDSEG_ARG(dx != nullptr, 7);
+    SSDSEG_ARG(lddx >= k, 8);
+    SSDSEG_ARG(dw != nullptr, 9);
+    SSDSEG_ARG(m > 0, 10);
+    SSDSEG_ARG(k > 0 && k % 4 == 0, 11);
+    SSDSEG_ARG(n > 0 && n % 4 == 0, 12);
+    SSDSEG_ARG(residual == nullptr || ldr >= k, 14);
+    // Measured on MI355X (profiles/r01 per-layer table): the fused kernel holds 16*NT more accumulator registers, so beyond
+    // NT = 3 only one block fits a CU and the single 32 KiB tile it keeps in flight cannot cover HBM latency (1.3-1.5 TB/s);
+    // with a single chunk (n <= 32) the per-row-tile set-up dominates.  It wins for 64 < n <= 96 (block 1: 933 -> 756 us);
+    // SSDSEG_PW_FUSED=1 forces it for every shape it supports (k <= 32, n <= 192; the parity tests run that way too).
+    static const bool force_fused = getenv("SSDSEG_PW_FUSED") != nullptr && getenv("SSDSEG_PW_FUSED")[0] == '1';
+    const bool fused = k <= 32 && n <= 192 && (force_fused || (n > 64 && n <= 96));
+    if (!fused) {
+        int rc = ssdseg_pwconv_bwd_weight(ctx, in, ldx, dy, ldy, dw, m, k, n);
+        if (rc) return rc;
+        return ssdseg_pwconv_bwd_data(ctx, dy, ldy, w, dx, lddx, m, k, n, residual, ldr, accumulate);
+    }
+    RowAArgs a{};
+    a.a0 = dy->g; a.a1 = dy->y; a.cs = dy->scale; a.ct = dy->shift; a.ck1 = dy->k1; a.ck0 = dy->k0; a.act = dy->act;
+    a.lda = ldy;
+    a.b = w; a.ldb = n;
+    a.out = dx; a.ldo = lddx;
+    a.residual = residual; a.ldr = ldr; a.accumulate = accumulate;
+    a.I = m; a.R = n; a.J = k;
+    a.xw = in->x; a.xws = in->scale; a.xwt = in->shift; a.xwact = in->act; a.ldxw = ldx;
+    const int mtiles = cdiv(m, BM);
+    int gy = 2 * ctx->num_cus;   // two resident blocks per CU (112 + 16*NT registers each); every block walks >= 1 row tile
+    if (gy > mtiles) gy = mtiles;
+    void* ws;
+    int rc = ssdseg_workspace(ctx, (size_t)gy * k * n * sizeof(float), &ws);
+    if (rc) return rc;
+    a.wpart = (float*)ws;
+    const dim3 grid(1, gy, 1);
+    const size_t lds = (size_t)(BM * AS + BK * 33) * sizeof(float);
+    const double streamed = dy->scale != nullptr ? 2.0 : 1.0;
+    const double cost_bytes = 4.0 * (streamed * m * n + 2.0 * m * k + 2.0 * k * n);
+    const double cost_flops = 4.0 * m * k * n;
+    const int nt = cdiv(n, 32);
+    const char* kname = "gemm_rowA_kernel<1, 1, 0, fused dW>";
+    switch (nt) {
+        case 1: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 1>), grid, dim3(256), lds, a); break;
+        case 2: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 2>), grid, dim3(256), lds, a); break;
+        case 3: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 3>), grid, dim3(256), lds, a); break;
+        case 4: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 4>), grid, dim3(256), lds, a); break;
+        case 5: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 5>), grid, dim3(256), lds, a); break;
+        default: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 6>), grid, dim3(256), lds, a); break;
+    }
+    SSDSEG_LAUNCH_CHECK();
+    if (gy == 1) {
+        SSDSEG_HIP(hipMemcpyAsync(dw, a.wpart, (size_t)k * n * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        return 0;
+    }
+    return ssdseg_colsum(ctx, a.wpart, gy, (long long)k * n, dw);
 }
 
 int ssdseg_pwconv_bwd_weight(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssdseg_gview* dy, int ldy, float* dw,

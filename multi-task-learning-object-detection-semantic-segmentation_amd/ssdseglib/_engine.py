@@ -214,10 +214,13 @@ class PwOp(Op):
     def bwd(self):
         s = self.inp.store
         gv = self.out_val.gview()
-        self.e.ctx.call("ssdseg_pwconv_bwd_weight", self.inp.view(), s.ld, gv, self.out.ld, self.dw, self.m, self.k, self.n)
         if s.need_grad:
+            # dx and dW in one call: for few input channels (the expand convs) one kernel reads the wide gradient once
             dx, acc = s.grad_slot()
-            self.e.ctx.call("ssdseg_pwconv_bwd_data", gv, self.out.ld, self.w, dx, s.ld, self.m, self.k, self.n, None, 0, acc)
+            self.e.ctx.call("ssdseg_pwconv_bwd", self.inp.view(), s.ld, gv, self.out.ld, self.w, dx, s.ld, self.dw, self.m, self.k, self.n,
+                            None, 0, acc)
+        else:
+            self.e.ctx.call("ssdseg_pwconv_bwd_weight", self.inp.view(), s.ld, gv, self.out.ld, self.dw, self.m, self.k, self.n)
 
 
 class Conv3Op(Op):
