@@ -409,6 +409,39 @@ int dw_bwd_impl(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, const ss
         return ssdseg_bn_bwd_finalize_launch(ctx, bnpart, nparts, c, (double)n * h * wdt, in->scale, bn->mean, bn->invstd, bn->dgamma,
                                              bn->dbeta, bn->k1, bn->k0);
     }
+    const bool march2_ok = dilation == 1 && stride == 2 && (long long)n * h * wdt * c < (1LL << 30);
+    if (march2_ok && (choice == 0 || choice == 1)) {
+        March2Geom mg;
+        const MarchLaunch ml = march2_geometry(n, h, wdt, c, g.ho, g.wo, &mg);
+        const int nparts = (int)ml.grid.x;
+        const bool fuse = bn != nullptr && !accumulate;
+        void* ws;
+        int rc = ssdseg_workspace(ctx, (size_t)nparts * 11 * c * sizeof(float), &ws);
+        if (rc) return rc;
+        float* part = (float*)ws;
+        float* bnpart = part + (size_t)nparts * 9 * c;
+#define DW_BWD_MARCH2(BN_, PT_, PL_)                                                                                                          \
+    SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_bwd_march2_kernel<BN_, PT_, PL_>), ml.grid, ml.block, ml.lds, mg, v, w, gv, dx, part,      \
+                  accumulate, fuse ? bn->mean : (const float*)nullptr, fuse ? bn->invstd : (const float*)nullptr,                          \
+                  fuse ? bnpart : (float*)nullptr)
+#define DW_BWD_MARCH2_P(BN_)                             \
+    do {                                                 \
+        if (g.pt == 0 && g.pl == 0) DW_BWD_MARCH2(BN_, 0, 0); \
+        else if (g.pt == 0) DW_BWD_MARCH2(BN_, 0, 1);    \
+        else if (g.pl == 0) DW_BWD_MARCH2(BN_, 1, 0);    \
+        else DW_BWD_MARCH2(BN_, 1, 1);                   \
+    } while (0)
+        if (fuse) DW_BWD_MARCH2_P(true);
+        else DW_BWD_MARCH2_P(false);
+#undef DW_BWD_MARCH2_P
+#undef DW_BWD_MARCH2
+        SSDSEG_LAUNCH_CHECK();
+        rc = ssdseg_colsum(ctx, part, nparts, 9LL * c, dw);
+        if (rc || !fuse) return rc;
+        *bn_done = true;
+        return ssdseg_bn_bwd_finalize_launch(ctx, bnpart, nparts, c, (double)n * h * wdt, in->scale, bn->mean, bn->invstd, bn->dgamma,
+                                             bn->dbeta, bn->k1, bn->k0);
+    }
     const LdsLaunch ll = stride == 1 ? lds_launch<1>(g) : lds_launch<2>(g);
     // measured on MI355X (profiles/): the fused LDS backward wins for stride 1 with few channel groups (big early layers,
     // decoder); with many channel groups or stride 2 its 256-VGPR footprint loses to the register-window kernel

@@ -228,4 +228,223 @@ inline MarchLaunch march_geometry(int n, int h, int w, int c, MarchGeom* g) {
     return l;
 }
 
+// ------------------------------------------------------------------------------------------------ stride 2
+// Same march over OUTPUT rows r: a thread owns one channel of 2 output columns (wo0, wo0+1) = 4 input columns
+// wi0 .. wi0+3 with wi0 = 2*wo0 - PL, and finalises the two input rows 2r - PT, 2r - PT + 1 per step:
+//   dx[2r-PT  ][wi0+j] = sum_{kh in {0,2}} sum_kw dy[r - kh/2][..] w[kh][kw]      (taps of matching parity only)
+//   dx[2r-PT+1][wi0+j] =                   sum_kw dy[r       ][..] w[1 ][kw]
+//   dW[0|1][kw] += a[2r-PT+(0|1)][wi0+2q+kw] * dy[r][wo0+q],   dW[2][kw] += a[2r-PT][wi0+2q+kw] * dy[r-1][wo0+q]
+// (the kh = 2 tap of output row r-1 reads input row 2r-PT, i.e. the first row of THIS step: dy row r-1 is kept).
+struct March2Stage {   // raw loads of one step: dy row r (3 columns of g, y) and x rows 2r-PT, 2r-PT+1 (5 columns each)
+    float g[3], y[3], x0[5], x1[5];
+};
+
+struct March2Geom {
+    int n, h, w, c, ho, wo;
+    int rows, chunks, wstrips, cb, spb, sblocks, sgroups;   // as MarchGeom, over the OUTPUT rows / 2-column output strips
+};
+
+template <bool BNFUSE, int PT, int PL>
+__global__ void __launch_bounds__(256) dw_bwd_march2_kernel(March2Geom gm, ViewDev in, const float* __restrict__ wgt, GViewDev dy,
+                                                             float* __restrict__ dx, float* __restrict__ dwpart, int accumulate,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             float* __restrict__ bnpart) {
+    extern __shared__ float mred[];   // [11][blockDim.x]
+    const BlockPos bpos = xcd_block_pos();
+    const int t = threadIdx.x;
+    const int sp = t / gm.cb, cl = t - sp * gm.cb;
+    const int ch = bpos.y * gm.cb + cl;
+    int sb = bpos.x;
+    const int sg = sb % gm.sgroups; sb /= gm.sgroups;
+    const int rc = sb % gm.chunks;
+    const int img = sb / gm.chunks;
+    const int ws = sg * gm.spb + sp;
+    const bool active = sp < gm.spb && ch < gm.c && ws < gm.wstrips && bpos.x < gm.sblocks;
+    const int chs = ch < gm.c ? ch : 0;
+
+    const bool iaff = in.scale != nullptr, gaff = dy.scale != nullptr;
+    if (!gaff) { dy.y = dy.g; dy.act = SSDSEG_ACT_NONE; }
+    const float ilo = act_lo(in.act), ihi = act_hi(in.act);
+    const float glo = act_lo(dy.act), ghi = act_hi(dy.act);
+    const float is = iaff ? in.scale[chs] : 1.f, it = iaff ? in.shift[chs] : 0.f;
+    const float gs = gaff ? dy.scale[chs] : 1.f, gt = gaff ? dy.shift[chs] : 0.f;
+    const float gk1 = gaff ? dy.k1[chs] : 0.f, gk0 = gaff ? dy.k0[chs] : 0.f;
+    float mu = 0.f, istd = 0.f;
+    if (BNFUSE) { mu = mean[chs]; istd = invstd[chs]; }
+    float wk[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wk[k] = wgt[k * gm.c + chs];
+    float dwacc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dwacc[k] = 0.f;
+    float bsum = 0.f, bxh = 0.f;
+
+    if (active) {
+        const int wo0 = ws * 2, wi0 = 2 * wo0 - PL;
+        const int r0 = rc * gm.rows;
+        const int r1 = r0 + gm.rows < gm.ho ? r0 + gm.rows : gm.ho;
+        // 32-bit byte offsets (launcher: n*h*w*c*4 < 2^32)
+        const unsigned ibase = (((unsigned)img * gm.h * gm.w) * gm.c + ch) * 4u;     // input-resolution tensors (x, dx)
+        const unsigned obase = (((unsigned)img * gm.ho * gm.wo) * gm.c + ch) * 4u;   // output-resolution tensors (g, y)
+        const unsigned irow = (unsigned)gm.w * gm.c * 4u, orow = (unsigned)gm.wo * gm.c * 4u;
+        bool dok[3], xok[5];
+        unsigned doff[3], xoff[5];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int col = wo0 - 1 + a;
+            dok[a] = col >= 0 && col < gm.wo;
+            doff[a] = (unsigned)(dok[a] ? col : 0) * gm.c * 4u;
+        }
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+            const int col = wi0 + b;
+            xok[b] = col >= 0 && col < gm.w;
+            xoff[b] = (unsigned)(xok[b] ? col : 0) * gm.c * 4u;
+        }
+        auto clampi = [](int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); };
+        auto issue = [&](int r, March2Stage& s) {   // rows clamped into the tensors; masked when consumed
+            const unsigned db = obase + (unsigned)clampi(r, gm.ho - 1) * orow;
+            const unsigned xb0 = ibase + (unsigned)clampi(2 * r - PT, gm.h - 1) * irow;
+            const unsigned xb1 = ibase + (unsigned)clampi(2 * r - PT + 1, gm.h - 1) * irow;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                s.g[a] = ldg_b(dy.g, db + doff[a]);
+                s.y[a] = ldg_b(dy.y, db + doff[a]);
+            }
+#pragma unroll
+            for (int b = 0; b < 5; ++b) {
+                s.x0[b] = ldg_b(in.x, xb0 + xoff[b]);
+                s.x1[b] = ldg_b(in.x, xb1 + xoff[b]);
+            }
+        };
+        auto make_dy = [&](int row, const float (&g)[3], const float (&y)[3], float (&d)[3]) {
+            const bool rok = row >= 0 && row < gm.ho;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float z = fmaf(gs, y[a], gt);
+                const float m = (z > glo && z < ghi) ? gs : 0.f;
+                const float v = fmaf(m, g[a], fmaf(gk1, y[a], gk0));
+                d[a] = (rok && dok[a]) ? v : 0.f;
+            }
+        };
+        float dprev[3], dcur[3];
+        {
+            March2Stage p;
+            issue(r0 - 1, p);
+            make_dy(r0 - 1, p.g, p.y, dprev);
+        }
+        auto step = [&](int r, March2Stage& cur, March2Stage& nxt) {
+            make_dy(r, cur.g, cur.y, dcur);
+            const int hi0 = 2 * r - PT, hi1 = hi0 + 1;
+            const bool rok0 = hi0 >= 0 && hi0 < gm.h, rok1 = hi1 < gm.h;   // hi1 >= 0 always
+            float xa0[5], xa1[5];
+#pragma unroll
+            for (int b = 0; b < 5; ++b) {
+                const float z0 = fminf(fmaxf(fmaf(is, cur.x0[b], it), ilo), ihi);
+                const float z1 = fminf(fmaxf(fmaf(is, cur.x1[b], it), ilo), ihi);
+                xa0[b] = (rok0 && xok[b]) ? z0 : 0.f;
+                xa1[b] = (rok1 && xok[b]) ? z1 : 0.f;
+            }
+            issue(r + 1, nxt);   // unconditional: see the stride-1 kernel
+            // ---- dx rows hi0 (kh in {0, 2}) and hi1 (kh = 1); column j: j even -> kw in {0, 2}, j odd -> kw = 1
+            float acc0[4], acc1[4];
+            // window index of dy column wo: wo - (wo0 - 1)
+            acc0[0] = fmaf(dcur[1], wk[0], fmaf(dcur[0], wk[2], fmaf(dprev[1], wk[6], dprev[0] * wk[8])));
+            acc0[1] = fmaf(dcur[1], wk[1], dprev[1] * wk[7]);
+            acc0[2] = fmaf(dcur[2], wk[0], fmaf(dcur[1], wk[2], fmaf(dprev[2], wk[6], dprev[1] * wk[8])));
+            acc0[3] = fmaf(dcur[2], wk[1], dprev[2] * wk[7]);
+            acc1[0] = fmaf(dcur[1], wk[3], dcur[0] * wk[5]);
+            acc1[1] = dcur[1] * wk[4];
+            acc1[2] = fmaf(dcur[2], wk[3], dcur[1] * wk[5]);
+            acc1[3] = dcur[2] * wk[4];
+            const unsigned ob0 = ibase + (unsigned)(rok0 ? hi0 : 0) * irow, ob1 = ibase + (unsigned)(rok1 ? hi1 : 0) * irow;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (rok0 && xok[j]) {
+                    if (dx != nullptr) {
+                        float* p = reinterpret_cast<float*>(reinterpret_cast<char*>(dx) + (ob0 + xoff[j]));
+                        if (accumulate) acc0[j] += *p;
+                        *p = acc0[j];
+                    }
+                    if (BNFUSE) {
+                        const float mg = (xa0[j] > ilo && xa0[j] < ihi) ? acc0[j] : 0.f;
+                        bsum += mg;
+                        bxh = fmaf(mg, (cur.x0[j] - mu) * istd, bxh);
+                    }
+                }
+                if (rok1 && xok[j]) {
+                    if (dx != nullptr) {
+                        float* p = reinterpret_cast<float*>(reinterpret_cast<char*>(dx) + (ob1 + xoff[j]));
+                        if (accumulate) acc1[j] += *p;
+                        *p = acc1[j];
+                    }
+                    if (BNFUSE) {
+                        const float mg = (xa1[j] > ilo && xa1[j] < ihi) ? acc1[j] : 0.f;
+                        bsum += mg;
+                        bxh = fmaf(mg, (cur.x1[j] - mu) * istd, bxh);
+                    }
+                }
+            }
+            // ---- dW over the two owned outputs q (dy window index q + 1)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    dwacc[0 * 3 + kw] = fmaf(xa0[2 * q + kw], dcur[q + 1], dwacc[0 * 3 + kw]);
+                    dwacc[1 * 3 + kw] = fmaf(xa1[2 * q + kw], dcur[q + 1], dwacc[1 * 3 + kw]);
+                    dwacc[2 * 3 + kw] = fmaf(xa0[2 * q + kw], dprev[q + 1], dwacc[2 * 3 + kw]);
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) dprev[a] = dcur[a];
+        };
+        March2Stage sa, sb2;
+        issue(r0, sa);
+        int r = r0;
+        for (; r + 1 < r1; r += 2) {
+            step(r, sa, sb2);
+            step(r + 1, sb2, sa);
+        }
+        if (r < r1) step(r, sa, sb2);
+    }
+
+    const int nth = blockDim.x;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) mred[k * nth + t] = dwacc[k];
+    if (BNFUSE) { mred[9 * nth + t] = bsum; mred[10 * nth + t] = bxh; }
+    __syncthreads();
+    if (sp == 0 && ch < gm.c) {
+        const int nv = BNFUSE ? 11 : 9;
+        for (int k = 0; k < nv; ++k) {
+            float s = 0.f;
+            for (int q = 0; q < gm.spb; ++q) s += mred[k * nth + q * gm.cb + cl];
+            if (k < 9) dwpart[((long long)bpos.x * 9 + k) * gm.c + ch] = s;
+            else bnpart[((long long)bpos.x * 2 + (k - 9)) * gm.c + ch] = s;
+        }
+    }
+}
+
+inline MarchLaunch march2_geometry(int n, int h, int w, int c, int ho, int wo, March2Geom* g) {
+    g->n = n; g->h = h; g->w = w; g->c = c; g->ho = ho; g->wo = wo;
+    g->wstrips = cdiv(wo, 2);
+    const int cchunks = cdiv(c, 256);
+    g->cb = cdiv(c, cchunks);
+    g->spb = 256 / g->cb;
+    if (g->spb < 1) g->spb = 1;
+    if (g->spb > g->wstrips) g->spb = g->wstrips;
+    g->sgroups = cdiv(g->wstrips, g->spb);
+    const int threads = ((g->cb * g->spb + 63) / 64) * 64;
+    const long long waves_per_chunkrow = (long long)n * g->sgroups * cchunks * (threads / 64);
+    int rows = ho;
+    while (rows > 8 && waves_per_chunkrow * cdiv(ho, rows) < 4096) rows = (rows + 1) / 2;
+    g->rows = rows;
+    g->chunks = cdiv(ho, rows);
+    g->sblocks = n * g->chunks * g->sgroups;
+    MarchLaunch l;
+    l.grid = dim3((unsigned)((g->sblocks + 7) & ~7), cchunks, 1);
+    l.block = dim3(threads, 1, 1);
+    l.lds = (size_t)11 * threads * sizeof(float);
+    return l;
+}
+
 }  // namespace
