@@ -363,6 +363,17 @@ int dw_bwd_choice() {
     return choice;
 }
 
+// forward kernel family: column-marching for every dense-tap conv whose tensors fit 32-bit byte offsets
+// (SSDSEG_DW_FWD=lds keeps the LDS-tiled kernels for A/B measurements)
+bool dw_fwd_use_march(int n, int h, int w, int c, int dilation) {
+    static int choice = -1;
+    if (choice < 0) {
+        const char* e = getenv("SSDSEG_DW_FWD");
+        choice = (e && !strcmp(e, "lds")) ? 1 : 0;
+    }
+    return choice == 0 && dilation == 1 && (long long)n * h * w * c < (1LL << 30);
+}
+
 struct BnFuse {   // BatchNorm-backward reduction of the layer feeding this depthwise conv, fused into its backward
     const float* mean;
     const float* invstd;
@@ -482,8 +493,14 @@ int ssdseg_dwconv_parts(int n, int h, int w, int c, int stride, int dilation, in
     DwGeom g;
     DwLaunch l;
     dw_geometry(n, h, w, c, stride, dilation, &g, &l);
-    if (dilation == 1) *nparts_host = (int)(stride == 1 ? lds_launch<1>(g) : lds_launch<2>(g)).grid.x;   // LDS-tiled kernels
-    else *nparts_host = (int)l.grid.x;                                                                   // gather kernels
+    if (dw_fwd_use_march(n, h, w, c, dilation)) {
+        March2Geom mg;
+        *nparts_host = (int)march_fwd_geometry(n, h, w, c, g.ho, g.wo, stride, &mg).grid.x;             // column-marching kernels
+    } else if (dilation == 1) {
+        *nparts_host = (int)(stride == 1 ? lds_launch<1>(g) : lds_launch<2>(g)).grid.x;                  // LDS-tiled kernels
+    } else {
+        *nparts_host = (int)l.grid.x;                                                                   // gather kernels
+    }
     return 0;
 }
 
@@ -507,7 +524,18 @@ int ssdseg_dwconv_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, fl
     // algorithmic traffic: read X, write Y, read W
     const double cost_bytes = 4.0 * ((double)n * h * wdt * c + (double)n * g.ho * g.wo * c + 9.0 * c);
     const double cost_flops = 18.0 * n * g.ho * g.wo * c;
-    if (dilation == 1 && stride == 1) {
+    if (dw_fwd_use_march(n, h, wdt, c, dilation)) {
+        March2Geom mg;
+        const MarchLaunch ml = march_fwd_geometry(n, h, wdt, c, g.ho, g.wo, stride, &mg);
+#define DW_FWD_MARCH(S_, PT_, PL_) \
+    SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_fwd_march_kernel<S_, PT_, PL_>), ml.grid, ml.block, ml.lds, mg, v, w, y, stats)
+        if (stride == 1) DW_FWD_MARCH(1, 1, 1);
+        else if (g.pt == 0 && g.pl == 0) DW_FWD_MARCH(2, 0, 0);
+        else if (g.pt == 0) DW_FWD_MARCH(2, 0, 1);
+        else if (g.pl == 0) DW_FWD_MARCH(2, 1, 0);
+        else DW_FWD_MARCH(2, 1, 1);
+#undef DW_FWD_MARCH
+    } else if (dilation == 1 && stride == 1) {
         const LdsLaunch ll = lds_launch<1>(g);
         SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_fwd_lds_kernel<1>), ll.grid, dim3(256), ll.lds_fwd, g, v, w, y, stats);
     } else if (dilation == 1) {

@@ -424,6 +424,165 @@ __global__ void __launch_bounds__(256) dw_bwd_march2_kernel(March2Geom gm, ViewD
     }
 }
 
+// ------------------------------------------------------------------------------------------------ forward
+// The same march for the forward conv: S = 1: 4 output columns per thread, rolling 3-row window of the activated input;
+// S = 2: 2 output columns (5 input columns), two new input rows per output row, the third is next step's first.
+// BN statistics (sum, sumsq of the raw output) stay in registers and leave as one partial row per block.
+// `gm` is a March2Geom in both cases (h, w input; ho, wo output; strips over output columns).
+template <int S, int PT, int PL>
+__global__ void __launch_bounds__(256) dw_fwd_march_kernel(March2Geom gm, ViewDev in, const float* __restrict__ wgt, float* __restrict__ y,
+                                                            float* __restrict__ stats) {
+    constexpr int OC = S == 1 ? 4 : 2;        // output columns per thread
+    constexpr int IC = (OC - 1) * S + 3;      // input columns per thread (6 | 5)
+    constexpr int NR = S;                     // new input rows per step
+    extern __shared__ float mred[];           // [2][blockDim.x]
+    const BlockPos bpos = xcd_block_pos();
+    const int t = threadIdx.x;
+    const int sp = t / gm.cb, cl = t - sp * gm.cb;
+    const int ch = bpos.y * gm.cb + cl;
+    int sb = bpos.x;
+    const int sg = sb % gm.sgroups; sb /= gm.sgroups;
+    const int rc = sb % gm.chunks;
+    const int img = sb / gm.chunks;
+    const int ws = sg * gm.spb + sp;
+    const bool active = sp < gm.spb && ch < gm.c && ws < gm.wstrips && bpos.x < gm.sblocks;
+    const int chs = ch < gm.c ? ch : 0;
+    const bool iaff = in.scale != nullptr;
+    const float ilo = act_lo(in.act), ihi = act_hi(in.act);
+    const float is = iaff ? in.scale[chs] : 1.f, it = iaff ? in.shift[chs] : 0.f;
+    float wk[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wk[k] = wgt[k * gm.c + chs];
+    float ssum = 0.f, ssq = 0.f;
+
+    if (active) {
+        const int wo0 = ws * OC, wi0 = wo0 * S - PL;
+        const int r0 = rc * gm.rows;
+        const int r1 = r0 + gm.rows < gm.ho ? r0 + gm.rows : gm.ho;
+        const unsigned ibase = (((unsigned)img * gm.h * gm.w) * gm.c + ch) * 4u;
+        const unsigned obase = (((unsigned)img * gm.ho * gm.wo) * gm.c + ch) * 4u;
+        const unsigned irow = (unsigned)gm.w * gm.c * 4u, orow = (unsigned)gm.wo * gm.c * 4u, ocol = (unsigned)gm.c * 4u;
+        bool xok[IC];
+        unsigned xoff[IC];
+#pragma unroll
+        for (int b = 0; b < IC; ++b) {
+            const int col = wi0 + b;
+            xok[b] = col >= 0 && col < gm.w;
+            xoff[b] = (unsigned)(xok[b] ? col : 0) * gm.c * 4u;
+        }
+        struct Stage { float x[NR][IC]; };
+        // the NR new input rows of output row r: S=1: row r + 1 - PT (= r+1-1 .. window rows r-PT, r-PT+1, r-PT+2);
+        // S=2: rows 2r - PT + 1, 2r - PT + 2  (row 2r - PT is the previous step's last row)
+        auto first_new = [&](int r) { return S == 1 ? r + 2 - PT : 2 * r - PT + 1; };
+        auto issue = [&](int r, Stage& s) {
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                int row = first_new(r) + q;
+                row = row < 0 ? 0 : (row > gm.h - 1 ? gm.h - 1 : row);
+                const unsigned rb = ibase + (unsigned)row * irow;
+#pragma unroll
+                for (int b = 0; b < IC; ++b) s.x[q][b] = ldg_b(in.x, rb + xoff[b]);
+            }
+        };
+        auto activate = [&](int row, const float (&raw)[IC], float (&a)[IC]) {
+            const bool rok = row >= 0 && row < gm.h;
+#pragma unroll
+            for (int b = 0; b < IC; ++b) {
+                const float z = fminf(fmaxf(fmaf(is, raw[b], it), ilo), ihi);
+                a[b] = (rok && xok[b]) ? z : 0.f;
+            }
+        };
+        // window rows: S=1: (r-PT, r-PT+1) carried, r-PT+2 new; S=2: (2r-PT) carried, 2r-PT+1, 2r-PT+2 new
+        float wa[3][IC];
+        {
+            Stage p;
+            // prologue: the carried rows of the first step, fetched through the same clamped loader
+            if (S == 1) {
+                // rows r0-PT and r0-PT+1 are "new rows" of the virtual steps r0-2 and r0-1
+                issue(r0 - 2, p); activate(r0 - PT, p.x[0], wa[0]);
+                issue(r0 - 1, p); activate(r0 - PT + 1, p.x[0], wa[1]);
+            } else {
+                issue(r0 - 1, p); activate(2 * r0 - PT, p.x[NR - 1], wa[0]);   // second new row of step r0-1 == 2*r0 - PT
+            }
+        }
+        auto step = [&](int r, Stage& cur, Stage& nxt) {
+            if (S == 1) {
+                activate(r + 2 - PT, cur.x[0], wa[2]);
+            } else {
+                activate(2 * r - PT + 1, cur.x[0], wa[1]);
+                activate(2 * r - PT + 2, cur.x[NR - 1], wa[2]);
+            }
+            issue(r + 1, nxt);   // unconditional (see the backward kernel)
+            const unsigned ob = obase + (unsigned)r * orow + (unsigned)wo0 * ocol;
+#pragma unroll
+            for (int j = 0; j < OC; ++j) {
+                float acc = 0.f;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) acc = fmaf(wa[kh][j * S + kw], wk[kh * 3 + kw], acc);
+                if (wo0 + j < gm.wo) {
+                    *reinterpret_cast<float*>(reinterpret_cast<char*>(y) + (ob + (unsigned)j * ocol)) = acc;
+                    ssum += acc;
+                    ssq = fmaf(acc, acc, ssq);
+                }
+            }
+            if (S == 1) {
+#pragma unroll
+                for (int b = 0; b < IC; ++b) { wa[0][b] = wa[1][b]; wa[1][b] = wa[2][b]; }
+            } else {
+#pragma unroll
+                for (int b = 0; b < IC; ++b) wa[0][b] = wa[2][b];
+            }
+        };
+        Stage sa, sb2;
+        issue(r0, sa);
+        int r = r0;
+        for (; r + 1 < r1; r += 2) {
+            step(r, sa, sb2);
+            step(r + 1, sb2, sa);
+        }
+        if (r < r1) step(r, sa, sb2);
+    }
+
+    if (stats != nullptr) {
+        const int nth = blockDim.x;
+        mred[t] = ssum;
+        mred[nth + t] = ssq;
+        __syncthreads();
+        if (sp == 0 && ch < gm.c) {
+            float s = 0.f, q = 0.f;
+            for (int k = 0; k < gm.spb; ++k) { s += mred[k * gm.cb + cl]; q += mred[nth + k * gm.cb + cl]; }
+            stats[((long long)bpos.x * 2 + 0) * gm.c + ch] = s;
+            stats[((long long)bpos.x * 2 + 1) * gm.c + ch] = q;
+        }
+    }
+}
+
+// forward geometry: strips of OC output columns
+inline MarchLaunch march_fwd_geometry(int n, int h, int w, int c, int ho, int wo, int stride, March2Geom* g) {
+    g->n = n; g->h = h; g->w = w; g->c = c; g->ho = ho; g->wo = wo;
+    g->wstrips = cdiv(wo, stride == 1 ? 4 : 2);
+    const int cchunks = cdiv(c, 256);
+    g->cb = cdiv(c, cchunks);
+    g->spb = 256 / g->cb;
+    if (g->spb < 1) g->spb = 1;
+    if (g->spb > g->wstrips) g->spb = g->wstrips;
+    g->sgroups = cdiv(g->wstrips, g->spb);
+    const int threads = ((g->cb * g->spb + 63) / 64) * 64;
+    const long long waves_per_chunkrow = (long long)n * g->sgroups * cchunks * (threads / 64);
+    int rows = ho;
+    while (rows > 8 && waves_per_chunkrow * cdiv(ho, rows) < 4096) rows = (rows + 1) / 2;
+    g->rows = rows;
+    g->chunks = cdiv(ho, rows);
+    g->sblocks = n * g->chunks * g->sgroups;
+    MarchLaunch l;
+    l.grid = dim3((unsigned)((g->sblocks + 7) & ~7), cchunks, 1);
+    l.block = dim3(threads, 1, 1);
+    l.lds = (size_t)2 * threads * sizeof(float);
+    return l;
+}
+
 inline MarchLaunch march2_geometry(int n, int h, int w, int c, int ho, int wo, March2Geom* g) {
     g->n = n; g->h = h; g->w = w; g->c = c; g->ho = ho; g->wo = wo;
     g->wstrips = cdiv(wo, 2);
