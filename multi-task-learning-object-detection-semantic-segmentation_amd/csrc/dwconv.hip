@@ -354,24 +354,18 @@ int ssdseg_bn_bwd_finalize_launch(ssdseg_ctx* ctx, const float* part, int nparts
 namespace {
 
 // SSDSEG_DW_BWD=march|lds|reg forces one backward kernel family (A/B measurements); default: measured best per shape
+// (read on every call, not cached: the parity tests flip it between calls)
 int dw_bwd_choice() {
-    static int choice = -1;
-    if (choice < 0) {
-        const char* e = getenv("SSDSEG_DW_BWD");
-        choice = !e ? 0 : (!strcmp(e, "march") ? 1 : (!strcmp(e, "lds") ? 2 : (!strcmp(e, "reg") ? 3 : 0)));
-    }
-    return choice;
+    const char* e = getenv("SSDSEG_DW_BWD");
+    return !e ? 0 : (!strcmp(e, "march") ? 1 : (!strcmp(e, "lds") ? 2 : (!strcmp(e, "reg") ? 3 : 0)));
 }
 
 // forward kernel family: column-marching for every dense-tap conv whose tensors fit 32-bit byte offsets
 // (SSDSEG_DW_FWD=lds keeps the LDS-tiled kernels for A/B measurements)
 bool dw_fwd_use_march(int n, int h, int w, int c, int dilation) {
-    static int choice = -1;
-    if (choice < 0) {
-        const char* e = getenv("SSDSEG_DW_FWD");
-        choice = (e && !strcmp(e, "lds")) ? 1 : 0;
-    }
-    return choice == 0 && dilation == 1 && (long long)n * h * w * c < (1LL << 30);
+    const char* e = getenv("SSDSEG_DW_FWD");
+    const bool lds = e != nullptr && !strcmp(e, "lds");
+    return !lds && dilation == 1 && (long long)n * h * w * c < (1LL << 30);
 }
 
 struct BnFuse {   // BatchNorm-backward reduction of the layer feeding this depthwise conv, fused into its backward

@@ -564,6 +564,19 @@ int pick_wn(int n, long long row_blocks) {
 
 int rowA_wn(int rows, int cols) { return pick_wn(cols, cdiv(rows, BM)); }
 
+#include "gemm_wres.h"
+
+// 1: the resident kernels where they measured faster (default); 0: SSDSEG_NO_WRES=1, general kernels everywhere (A/B
+// measurements); 2: SSDSEG_WRES_FORCE=1, resident kernels for every shape that fits (the parity tests run that way)
+int wres_mode() {
+    // (read on every call, not cached: the parity tests flip these between calls)
+    const int mode = (getenv("SSDSEG_NO_WRES") != nullptr && getenv("SSDSEG_NO_WRES")[0] == '1')
+                                ? 0
+                                : ((getenv("SSDSEG_WRES_FORCE") != nullptr && getenv("SSDSEG_WRES_FORCE")[0] == '1') ? 2 : 1);
+    return mode;
+}
+bool wres_enabled() { return wres_mode() != 0; }
+
 // row-tile slots per column tile: enough blocks to fill the chip (~8 per CU), few enough that the BN partial
 // table stays short
 int rowA_grid_y(int rows, int cols) {
@@ -587,6 +600,25 @@ int launch_rowA(ssdseg_ctx* ctx, const RowAArgs& a) {
     const double cost_bytes = 4.0 * (streamed * a.I * a.R + (double)a.I * a.J + (double)a.R * a.J);
     const double cost_flops = 2.0 * a.I * a.R * a.J;
     char kbuf[64];
+    // Measured per layer on MI355X (profiles/r01_wres_vs_general_per_layer.txt): the resident kernel wins when every wave
+    // streams several row tiles (>= ~500k rows: the 240x320 and 120x160 stages at batch 32) and loses 10-30 % below that,
+    // where its once-per-block weight load is not amortised; its 5-tile backward variant needs > 256 registers.
+    if (LD == 0 && wres_lds_bytes(a.R, wn) > 0 && (wres_mode() == 2 || (wres_mode() == 1 && a.I >= 500000 && !(MODE == 1 && wn >= 4)))) {
+        // whole weight slab resident in LDS, barrier-free per-wave streaming (gemm_wres.h); same grid, same partial rows
+        const size_t wl = wres_lds_bytes(a.R, wn);
+        snprintf(kbuf, sizeof(kbuf), "gemm_wres_kernel<%d, %d, 0>", wn, MODE);
+        const char* wname = ctx->timing ? ssdseg_intern(kbuf) : "";
+        constexpr int WM = LD == 0 ? MODE : 0;   // (only instantiated for LD == 0)
+        switch (wn) {
+            case 1: SSDSEG_LAUNCH_NAMED(ctx, wname, cost_bytes, cost_flops, (gemm_wres_kernel<1, WM, 0>), grid, dim3(256), wl, a); break;
+            case 2: SSDSEG_LAUNCH_NAMED(ctx, wname, cost_bytes, cost_flops, (gemm_wres_kernel<2, WM, 0>), grid, dim3(256), wl, a); break;
+            case 3: SSDSEG_LAUNCH_NAMED(ctx, wname, cost_bytes, cost_flops, (gemm_wres_kernel<3, WM, 0>), grid, dim3(256), wl, a); break;
+            case 4: SSDSEG_LAUNCH_NAMED(ctx, wname, cost_bytes, cost_flops, (gemm_wres_kernel<4, WM, 0>), grid, dim3(256), wl, a); break;
+            default: SSDSEG_LAUNCH_NAMED(ctx, wname, cost_bytes, cost_flops, (gemm_wres_kernel<5, WM, 0>), grid, dim3(256), wl, a); break;
+        }
+        SSDSEG_LAUNCH_CHECK();
+        return 0;
+    }
     snprintf(kbuf, sizeof(kbuf), "gemm_rowA_kernel<%d, %d, %d>", wn, MODE, LD);
     const char* kname = ctx->timing ? ssdseg_intern(kbuf) : "";
     switch (wn) {
@@ -739,12 +771,13 @@ int ssdseg_pwconv_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssd
     SSDSEG_ARG(k > 0 && k % 4 == 0, 11);
     SSDSEG_ARG(n > 0 && n % 4 == 0, 12);
     SSDSEG_ARG(residual == nullptr || ldr >= k, 14);
-    // Measured on MI355X (profiles/r01 per-layer table): the fused kernel holds 16*NT more accumulator registers, so beyond
-    // NT = 3 only one block fits a CU and the single 32 KiB tile it keeps in flight cannot cover HBM latency (1.3-1.5 TB/s);
-    // with a single chunk (n <= 32) the per-row-tile set-up dominates.  It wins for 64 < n <= 96 (block 1: 933 -> 756 us);
-    // SSDSEG_PW_FUSED=1 forces it for every shape it supports (k <= 32, n <= 192; the parity tests run that way too).
-    static const bool force_fused = getenv("SSDSEG_PW_FUSED") != nullptr && getenv("SSDSEG_PW_FUSED")[0] == '1';
-    const bool fused = k <= 32 && n <= 192 && (force_fused || (n > 64 && n <= 96));
+    // Measured per layer on MI355X (profiles/r01_wres_vs_general_per_layer.txt): the fused pass wins on the big early layers
+    // (blocks 1-3 at batch 32: 760 -> 642, 492 -> 462, 456 -> 354 us against wgrad + bwd_data), is even at 153,600 rows and
+    // loses with a single 32-column chunk, where the per-tile set-up dominates.  Its 16*NT accumulator registers cap the
+    // occupancy at 1-2 waves per SIMD, which is why it stops at ~3.4 TB/s.  SSDSEG_PW_FUSED=1 forces it for every shape it
+    // supports (k <= 32, n <= 192); the parity tests run both ways.
+    const bool force_fused = getenv("SSDSEG_PW_FUSED") != nullptr && getenv("SSDSEG_PW_FUSED")[0] == '1';
+    const bool fused = k <= 32 && n <= 192 && (force_fused || (n > 32 && m >= 500000));
     if (!fused) {
         int rc = ssdseg_pwconv_bwd_weight(ctx, in, ldx, dy, ldy, dw, m, k, n);
         if (rc) return rc;
@@ -771,6 +804,24 @@ int ssdseg_pwconv_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssd
     const double cost_bytes = 4.0 * (streamed * m * n + 2.0 * m * k + 2.0 * k * n);
     const double cost_flops = 4.0 * m * k * n;
     const int nt = cdiv(n, 32);
+    const size_t wl = wres_enabled() ? wres_lds_bytes(n, 1) : 0;
+    if (wl > 0) {
+        const char* wname = "gemm_wres_kernel<1, 1, fused dW>";
+        switch (nt) {
+            case 1: SSDSEG_LAUNCH_NAMED(ctx, wname, cost_bytes, cost_flops, (gemm_wres_kernel<1, 1, 1>), grid, dim3(256), wl, a); break;
+            case 2: SSDSEG_LAUNCH_NAMED(ctx, wname, cost_bytes, cost_flops, (gemm_wres_kernel<1, 1, 2>), grid, dim3(256), wl, a); break;
+            case 3: SSDSEG_LAUNCH_NAMED(ctx, wname, cost_bytes, cost_flops, (gemm_wres_kernel<1, 1, 3>), grid, dim3(256), wl, a); break;
+            case 4: SSDSEG_LAUNCH_NAMED(ctx, wname, cost_bytes, cost_flops, (gemm_wres_kernel<1, 1, 4>), grid, dim3(256), wl, a); break;
+            case 5: SSDSEG_LAUNCH_NAMED(ctx, wname, cost_bytes, cost_flops, (gemm_wres_kernel<1, 1, 5>), grid, dim3(256), wl, a); break;
+            default: SSDSEG_LAUNCH_NAMED(ctx, wname, cost_bytes, cost_flops, (gemm_wres_kernel<1, 1, 6>), grid, dim3(256), wl, a); break;
+        }
+        SSDSEG_LAUNCH_CHECK();
+        if (gy == 1) {
+            SSDSEG_HIP(hipMemcpyAsync(dw, a.wpart, (size_t)k * n * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+            return 0;
+        }
+        return ssdseg_colsum(ctx, a.wpart, gy, (long long)k * n, dw);
+    }
     const char* kname = "gemm_rowA_kernel<1, 1, 0, fused dW>";
     switch (nt) {
         case 1: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 1>), grid, dim3(256), lds, a); break;

@@ -13,9 +13,14 @@ for p in (REPO, PKG):
 
 GOLDEN = os.path.join(REPO, "tests", "golden")
 
-# parity tests exercise the fused dx+dW pointwise backward kernel on every shape it supports (the product's default
-# dispatch only takes it where it measured faster; shapes outside its range run the separate kernels either way)
-os.environ.setdefault("SSDSEG_PW_FUSED", "1")
+# Kernel-family switches of the C library (read on every call): the per-kernel parity tests run each case once per family,
+# because the product's default dispatch picks a family per shape by measured speed and would leave the others untested.
+KERNEL_FAMILIES = {
+    "default": {},
+    "general": {"SSDSEG_NO_WRES": "1", "SSDSEG_DW_FWD": "lds", "SSDSEG_DW_BWD": "lds"},
+    "general-reg": {"SSDSEG_NO_WRES": "1", "SSDSEG_DW_FWD": "lds", "SSDSEG_DW_BWD": "reg"},
+    "resident-fused": {"SSDSEG_WRES_FORCE": "1", "SSDSEG_PW_FUSED": "1"},
+}
 
 
 def pytest_configure(config):
@@ -40,3 +45,12 @@ def ctx():
 @pytest.fixture()
 def rng():
     return np.random.default_rng(1993)
+
+
+@pytest.fixture(params=list(KERNEL_FAMILIES))
+def kernel_family(request, monkeypatch):
+    for k in ("SSDSEG_NO_WRES", "SSDSEG_WRES_FORCE", "SSDSEG_PW_FUSED", "SSDSEG_DW_FWD", "SSDSEG_DW_BWD"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in KERNEL_FAMILIES[request.param].items():
+        monkeypatch.setenv(k, v)
+    return request.param

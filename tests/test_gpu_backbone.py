@@ -43,7 +43,7 @@ def rel(a, b):
 
 
 @pytest.mark.parametrize("batch,shape", [(2, (80, 96, 3)), (3, (96, 128, 3))])
-def test_backbone_forward_backward_parity(ctx, rng, batch, shape):
+def test_backbone_forward_backward_parity(ctx, rng, kernel_family, batch, shape):
     from ssdseglib import _engine as E
     model = build_backbone(shape)
     # perturb BN affine so gamma/beta gradients and shifts are exercised

@@ -61,7 +61,7 @@ DW_CASES = [
 
 @pytest.mark.parametrize("n,h,w,c,s,d", DW_CASES)
 @pytest.mark.parametrize("act", [O.ACT_RELU6, O.ACT_NONE])
-def test_dwconv_fwd_bwd(ctx, rng, n, h, w, c, s, d, act):
+def test_dwconv_fwd_bwd(ctx, rng, kernel_family, n, h, w, c, s, d, act):
     from ssdseglib import _hip as H
     x, sc, sh, a = make_view_inputs(rng, (n, h, w, c), act)
     wgt = rng.normal(0, 0.3, (3, 3, c)).astype(np.float32)
@@ -139,7 +139,7 @@ PW_CASES = [
 
 
 @pytest.mark.parametrize("m,k,n", PW_CASES)
-def test_pwconv_fwd_bwd(ctx, rng, m, k, n):
+def test_pwconv_fwd_bwd(ctx, rng, kernel_family, m, k, n):
     from ssdseglib import _hip as H
     act = O.ACT_RELU6
     x, sc, sh, a = make_view_inputs(rng, (m, k), act)
