@@ -202,6 +202,30 @@ def cpu_baseline(workload, sample_batch=1):
                        f"passes on 1; {dt:.1f} s")
 
 
+def pmc_traffic(kernel: str, workload: str, batch: int):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this same workload.
+
+    FETCH_SIZE / WRITE_SIZE cannot be collected inside a timed run (separate `--pmc` passes, never together with other trace
+    domains), so they come from profiles/<round>_pmc_traffic_<workload>_b<batch>.json -- written by scripts/gpu_measure.sh +
+    scripts/pmc_summary.py with the gfx950 corrections of /opt/skills/guides/MI355X_MICROARCH.md -- and are averaged over the
+    launches of that kernel symbol exactly like `achieved`.  None when no summary for this workload/batch is committed or the
+    kernel symbol is not in it."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "profiles", f"r*_pmc_traffic_{workload}_b{batch}.json")))
+    if not files:
+        return None, None
+    try:
+        kernels = json.load(open(files[-1]))["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None, None
+    key = kernel.strip("()")
+    row = kernels.get(key)
+    if row is None:
+        return None, None
+    return round(row["hbm_bytes_per_launch"], 1), os.path.relpath(files[-1], here)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -295,11 +319,12 @@ def main():
             tfs = dom["flops"] / dom["count"] / (avg_ms * 1e-3) / 1e12
             hbm_frac, mfma_frac = gbs / HBM_PEAK_GBS, tfs / MFMA_F32_PEAK_TFLOPS
             bound = "mfma" if mfma_frac > hbm_frac else "hbm"
+            traffic, traffic_src = pmc_traffic(name, args.workload, args.batch)
             out["roofline"] = {
                 "kernel": name, "bound": bound,
                 "achieved": round(tfs if bound == "mfma" else gbs, 2), "peak": MFMA_F32_PEAK_TFLOPS if bound == "mfma" else HBM_PEAK_GBS,
                 "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": round(mfma_frac if bound == "mfma" else hbm_frac, 4),
-                "traffic": None, "launches": dom["count"], "avg_launch_ms": round(avg_ms, 4),
+                "traffic": traffic, "traffic_source": traffic_src, "launches": dom["count"], "avg_launch_ms": round(avg_ms, 4),
                 "share_of_kernel_time": round(survey[dominant]["ms"] / total_ms, 4),
                 "algorithmic_bytes_per_launch": dom["bytes"] / dom["count"], "flops_per_launch": dom["flops"] / dom["count"],
             }

@@ -209,11 +209,13 @@ __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
             rw[i] = rem - rh[i] * p.convW;
         }
     }
-    f32x16 acc[WN];
+    f32x16 acc[WN], accb;
 #pragma unroll
     for (int nt = 0; nt < WN; ++nt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accb[e] = 0.f;
 
     if (FUSEW) {
         const float xlo = act_lo(p.xwact), xhi = act_hi(p.xwact);
@@ -251,7 +253,9 @@ __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
 #pragma unroll
                 for (int nt = 0; nt < WN; ++nt) {
                     const float bv = bcol[(kk * 8 + jj) * BS + nt * 32];
-                    acc[nt] = mfma32(av[jj], bv, acc[nt]);
+                    // one column tile: alternate between two accumulators so consecutive MFMAs are independent
+                    if (WN == 1 && (jj & 1)) accb = mfma32(av[jj], bv, accb);
+                    else acc[nt] = mfma32(av[jj], bv, acc[nt]);
                 }
             }
         }
@@ -262,6 +266,10 @@ __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
             if (kt < KT) kstep(kt, wacc[kt]);
     } else {
         for (int kt = 0; kt < KT; ++kt) kstep(kt, wacc[0]);
+    }
+    if (WN == 1) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[0][e] += accb[e];
     }
 
     // ---------------- epilogue: C/D layout col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
@@ -619,7 +627,7 @@ int launch_rowA(ssdseg_ctx* ctx, const RowAArgs& a) {
         SSDSEG_LAUNCH_CHECK();
         return 0;
     }
-    snprintf(kbuf, sizeof(kbuf), "gemm_rowA_kernel<%d, %d, %d>", wn, MODE, LD);
+    snprintf(kbuf, sizeof(kbuf), "gemm_rowA_kernel<%d, %d, %d, 0>", wn, MODE, LD);   // = the symbol rocprofv3 shows
     const char* kname = ctx->timing ? ssdseg_intern(kbuf) : "";
     switch (wn) {
         case 1: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, MODE, LD>), grid, dim3(256), lds, a); break;
@@ -806,7 +814,9 @@ int ssdseg_pwconv_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssd
     const int nt = cdiv(n, 32);
     const size_t wl = wres_enabled() ? wres_lds_bytes(n, 1) : 0;
     if (wl > 0) {
-        const char* wname = "gemm_wres_kernel<1, 1, fused dW>";
+        char wbuf[64];
+        snprintf(wbuf, sizeof(wbuf), "gemm_wres_kernel<1, 1, %d>", nt > 6 ? 6 : nt);   // NT > 0: fused dW
+        const char* wname = ctx->timing ? ssdseg_intern(wbuf) : "";
         switch (nt) {
             case 1: SSDSEG_LAUNCH_NAMED(ctx, wname, cost_bytes, cost_flops, (gemm_wres_kernel<1, 1, 1>), grid, dim3(256), wl, a); break;
             case 2: SSDSEG_LAUNCH_NAMED(ctx, wname, cost_bytes, cost_flops, (gemm_wres_kernel<1, 1, 2>), grid, dim3(256), wl, a); break;
@@ -822,7 +832,9 @@ int ssdseg_pwconv_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssd
         }
         return ssdseg_colsum(ctx, a.wpart, gy, (long long)k * n, dw);
     }
-    const char* kname = "gemm_rowA_kernel<1, 1, 0, fused dW>";
+    char fbuf[64];
+    snprintf(fbuf, sizeof(fbuf), "gemm_rowA_kernel<1, 1, 0, %d>", nt > 6 ? 6 : nt);   // NT > 0: fused dW
+    const char* kname = ctx->timing ? ssdseg_intern(fbuf) : "";
     switch (nt) {
         case 1: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 1>), grid, dim3(256), lds, a); break;
         case 2: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 2>), grid, dim3(256), lds, a); break;
