@@ -83,6 +83,10 @@ int ssdseg_device_count(int* count_host);
 int ssdseg_ctx_create(int device, void* stream, ssdseg_ctx** out_host);
 int ssdseg_ctx_destroy(ssdseg_ctx* ctx);
 int ssdseg_ctx_sync(ssdseg_ctx* ctx);
+/* Weight-gradient kernels run on an internal side stream, concurrently with the rest of the backward pass.  Every entry point
+ * that synchronises, copies, records an event or runs the optimizer joins it implicitly; a caller that hands the gradient
+ * buffers to ANOTHER library on the ctx stream (the RCCL all-reduce of torch.distributed) calls this first. */
+int ssdseg_ctx_join(ssdseg_ctx* ctx);
 int ssdseg_ctx_reserve(ssdseg_ctx* ctx, size_t workspace_bytes);
 int ssdseg_ctx_device_name(ssdseg_ctx* ctx, char* buf_host, size_t buf_len);
 int ssdseg_malloc(ssdseg_ctx* ctx, size_t bytes, void** out_host);

@@ -38,6 +38,7 @@ extern "C" int ssdseg_adam_step(ssdseg_ctx* ctx, float* params, const float* gra
     SSDSEG_ARG(params && grads && m && v, 2);
     SSDSEG_ARG(step >= 1, 11);
     if (count == 0) return 0;
+    { int jrc = ssdseg_join(ctx); if (jrc) return jrc; }   // weight gradients may still be in flight on the side stream
     const double alpha = (double)lr * sqrt(1.0 - pow((double)beta2, step)) / (1.0 - pow((double)beta1, step));
     const size_t n4 = count / 4;
     size_t blocks = (n4 + 255) / 256;

@@ -18,7 +18,22 @@ struct ssdseg_ctx {
     int num_cus;
     bool capturing;
     ssdseg_timing* timing;  // non-null while kernel timing is enabled
+    // Side stream for work that is off the critical path of the backward pass (weight gradients: nothing reads dW before the
+    // optimizer).  ssdseg_side_begin() makes the side stream wait for everything queued so far and redirects `stream` /
+    // `workspace` to it; ssdseg_side_end() restores them; ssdseg_join() makes the main stream wait for the side work and is
+    // called by every entry point that synchronises, copies or reads gradients.
+    hipStream_t side_stream;
+    hipEvent_t ev_fork, ev_join;
+    void* side_workspace;
+    size_t side_workspace_bytes;
+    bool side_ok, side_on, side_pending;
 };
+
+extern "C" {
+bool ssdseg_side_begin(ssdseg_ctx* ctx);   // true when launches are now redirected to the side stream
+void ssdseg_side_end(ssdseg_ctx* ctx);
+int ssdseg_join(ssdseg_ctx* ctx);
+}
 
 // Brackets one kernel launch with HIP events on the ctx stream when timing is enabled (bench.py's roofline leg);
 // `bytes`/`flops` are the ALGORITHMIC traffic / work of this launch (formulas: DESIGN.md "Kernels").

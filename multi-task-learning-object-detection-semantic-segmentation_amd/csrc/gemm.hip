@@ -59,6 +59,10 @@ struct RowAArgs {
     const float* xwt;
     int xwact, ldxw;
     float* wpart;
+    // split-K (gridDim.z > 1): block z reduces the steps [z*ksteps, (z+1)*ksteps) and writes its raw partial tile to
+    // kpart[z][I][J]; bias / residual / accumulate / statistics then belong to splitk_reduce_kernel
+    int ksteps;
+    float* kpart;
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -229,13 +233,15 @@ __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
             xop[s] = ok ? fminf(fmaxf(fmaf(xs, v, xt), xlo), xhi) : 0.f;
         }
     }
-    load_tiles(0);
+    const int kt0 = gridDim.z > 1 ? (int)blockIdx.z * p.ksteps : 0;
+    const int kt1 = gridDim.z > 1 ? (kt0 + p.ksteps < KT ? kt0 + p.ksteps : KT) : KT;
+    load_tiles(kt0);
     // one 32-deep reduction step; `wtile` = which dW accumulator this step feeds (a compile-time constant in the fused loop)
     auto kstep = [&](int kt, f32x16& wtile) {
         __syncthreads();
         store_tiles();
         __syncthreads();
-        if (kt + 1 < KT) load_tiles(kt + 1);
+        if (kt + 1 < kt1) load_tiles(kt + 1);
         if (FUSEW) {
             // dW tile kt: rows of the reduction = this wave's 32 tile rows, B operand dy[row][32*kt + li] straight from As
             const float* dcol = As + (wave * 32 + hh) * AS + li;
@@ -244,18 +250,31 @@ __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
         }
         const float* arow = As + (wave * 32 + li) * AS + 4 * hh;
         const float* bcol = Bs + (4 * hh) * BS + li;
+        // Operand fragments are read from LDS one 8-deep group AHEAD of the MFMAs that use them (two register sets).  Left
+        // to itself the compiler put each ds_read right in front of its MFMA with an s_waitcnt lgkmcnt(0), so the matrix
+        // pipe idled for an LDS round trip every 1-2 instructions (38-59 TFLOP/s on the compute-bound layers).
+        float4 afr[2];
+        float bfr[2][4][WN];
+        auto fetch = [&](int kk, int buf) {
+            afr[buf] = ld4(arow + kk * 8);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int nt = 0; nt < WN; ++nt) bfr[buf][jj][nt] = bcol[(kk * 8 + jj) * BS + nt * 32];
+        };
+        fetch(0, 0);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            const float4 a4 = ld4(arow + kk * 8);
-            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+            if (kk + 1 < 4) fetch(kk + 1, (kk + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);   // keep the reads of group kk+1 in front of the MFMAs of group kk
+            const float av[4] = {afr[kk & 1].x, afr[kk & 1].y, afr[kk & 1].z, afr[kk & 1].w};
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
 #pragma unroll
                 for (int nt = 0; nt < WN; ++nt) {
-                    const float bv = bcol[(kk * 8 + jj) * BS + nt * 32];
                     // one column tile: alternate between two accumulators so consecutive MFMAs are independent
-                    if (WN == 1 && (jj & 1)) accb = mfma32(av[jj], bv, accb);
-                    else acc[nt] = mfma32(av[jj], bv, acc[nt]);
+                    if (WN == 1 && (jj & 1)) accb = mfma32(av[jj], bfr[kk & 1][jj][nt], accb);
+                    else acc[nt] = mfma32(av[jj], bfr[kk & 1][jj][nt], acc[nt]);
                 }
             }
         }
@@ -265,7 +284,7 @@ __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
         for (int kt = 0; kt < NT; ++kt)
             if (kt < KT) kstep(kt, wacc[kt]);
     } else {
-        for (int kt = 0; kt < KT; ++kt) kstep(kt, wacc[0]);
+        for (int kt = kt0; kt < kt1; ++kt) kstep(kt, wacc[0]);
     }
     if (WN == 1) {
 #pragma unroll
@@ -282,6 +301,10 @@ __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
                 const int m = m0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
                 if (m < p.I) {
                     float v = acc[nt][e];
+                    if (gridDim.z > 1) {   // split-K partial: raw sums only
+                        p.kpart[((long long)blockIdx.z * p.I + m) * p.J + j] = v;
+                        continue;
+                    }
                     if (STEM && p.bias) v += p.bias[j];
                     if (MODE == 1) {
                         if (p.residual) v += p.residual[(long long)m * p.ldr + j];
@@ -504,11 +527,22 @@ __global__ void __launch_bounds__(256) gemm_wgrad_kernel(WGradArgs p) {
         if (mrow + BRT < mend) load_tiles(mrow + BRT);
         const float* xa = Xs + (wr * RW + hh) * BI + wi * 32 + li;
         const float* yb = Ys + (wr * RW + hh) * BJ + li;
+        // fragments of step st + 2 are read while the MFMAs of step st run (see gemm_rowA_kernel: no per-MFMA LDS round trip)
+        constexpr int PF = 2, NST = RW / 2;
+        float afr[PF + 1], bfr[PF + 1][WN];
+        auto fetch = [&](int st, int buf) {
+            afr[buf] = xa[(2 * st) * BI];
 #pragma unroll
-        for (int st = 0; st < RW / 2; ++st) {
-            const float av = xa[(2 * st) * BI];
+            for (int nt = 0; nt < WN; ++nt) bfr[buf][nt] = yb[(2 * st) * BJ + nt * 32];
+        };
 #pragma unroll
-            for (int nt = 0; nt < WN; ++nt) acc[nt] = mfma32(av, yb[(2 * st) * BJ + nt * 32], acc[nt]);
+        for (int q = 0; q < PF; ++q) fetch(q, q);
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            if (st + PF < NST) fetch(st + PF, (st + PF) % (PF + 1));
+            __builtin_amdgcn_sched_barrier(0);   // keep those reads in front of this step's MFMAs
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt) acc[nt] = mfma32(afr[st % (PF + 1)], bfr[st % (PF + 1)][nt], acc[nt]);
         }
     }
 
@@ -595,10 +629,93 @@ int rowA_grid_y(int rows, int cols) {
     return mtiles < gy ? mtiles : gy;
 }
 
+// out[m][j] = sum_z part[z][m][j] (+ residual) (+ previous out), float4 per thread, plus (optionally) the BatchNorm statistics
+// of the result as one partial row per block -- the tail of a split-K launch.  J % 4 == 0, J <= 1024, 16-byte aligned rows.
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ part, int S, int I, int J, float* __restrict__ out,
+                                                             int ldo, const float* __restrict__ residual, int ldr, int accumulate,
+                                                             float* __restrict__ stats) {
+    __shared__ float4 sred[2 * 256];
+    const int cv = J / 4;
+    const int rpp = 256 / cv;   // rows per pass
+    const int t = threadIdx.x;
+    const int r = t / cv, c4 = t - r * cv;
+    const bool act = r < rpp;
+    float4 s = f4(0.f), q = f4(0.f);
+    const int mtiles = (I + BM - 1) / BM;
+    for (int tile = blockIdx.x; tile < mtiles; tile += gridDim.x) {
+        const int rend = (tile + 1) * BM < I ? (tile + 1) * BM : I;
+        for (int row = tile * BM + r; act && row < rend; row += rpp) {
+            float4 v = f4(0.f);
+            for (int z = 0; z < S; ++z) {
+                const float4 pz = ld4(part + ((long long)z * I + row) * J + c4 * 4);
+                v.x += pz.x; v.y += pz.y; v.z += pz.z; v.w += pz.w;
+            }
+            if (residual != nullptr) {
+                const float4 rz = ld4(residual + (long long)row * ldr + c4 * 4);
+                v.x += rz.x; v.y += rz.y; v.z += rz.z; v.w += rz.w;
+            }
+            float* o = out + (long long)row * ldo + c4 * 4;
+            if (accumulate) {
+                const float4 pv = ld4(o);
+                v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w;
+            }
+            st4(o, v);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            q.x = fmaf(v.x, v.x, q.x); q.y = fmaf(v.y, v.y, q.y); q.z = fmaf(v.z, v.z, q.z); q.w = fmaf(v.w, v.w, q.w);
+        }
+    }
+    if (stats == nullptr) return;
+    sred[t] = s;
+    sred[256 + t] = q;
+    __syncthreads();
+    if (t < cv) {   // r == 0: fold the block's row lanes in a fixed order
+        float4 a = f4(0.f), b = f4(0.f);
+        for (int k = 0; k < rpp; ++k) {
+            const float4 x = sred[k * cv + t], y = sred[256 + k * cv + t];
+            a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+            b.x += y.x; b.y += y.y; b.z += y.z; b.w += y.w;
+        }
+        st4(stats + ((long long)blockIdx.x * 2 + 0) * J + t * 4, a);
+        st4(stats + ((long long)blockIdx.x * 2 + 1) * J + t * 4, b);
+    }
+}
+
+// Off by default: measured on MI355X it is a wash (backbone step 14.68 ms without, 14.93 ms with) -- the operand re-reads it
+// removes were already served by the 256 MiB Infinity Cache, and the partial tiles + reduce kernel cost what was saved.
+// SSDSEG_SPLITK=1 enables it (read per call; the parity tests run that family too).
+bool splitk_enabled() { return getenv("SSDSEG_SPLITK") != nullptr && getenv("SSDSEG_SPLITK")[0] == '1'; }
+
 template <int MODE, int LD>
-int launch_rowA(ssdseg_ctx* ctx, const RowAArgs& a) {
-    const int wn = rowA_wn(a.I, a.J);
-    dim3 grid(cdiv(a.J, 32 * wn), rowA_grid_y(a.I, a.J), 1);
+int launch_rowA(ssdseg_ctx* ctx, const RowAArgs& a0) {
+    RowAArgs a = a0;
+    int wn = rowA_wn(a.I, a.J);
+    const int nparts = rowA_grid_y(a.I, a.J);   // BN-statistics partial rows the caller allocated: fixed by (I, J) alone
+    int splits = 1;
+    // Few row tiles and a long reduction (the 30x40 / 15x20 stages): the default picks narrow column tiles to get enough blocks,
+    // so every column tile re-reads the (up to 960-wide, two-tensor) streamed operand -- 3-5x the algorithmic traffic, bound by
+    // L2.  Here the tile spans all columns (operand read once) and the reduction is split across blocks instead; a small second
+    // kernel sums the partial tiles and takes over bias-free epilogue duties (residual, accumulate, BN statistics).
+    if (LD == 0 && splitk_enabled() && a.R >= 256 && a.J <= 160 && a.J % 4 == 0 && a.ldo % 4 == 0 && ((uintptr_t)a.out & 15) == 0 &&
+        (a.residual == nullptr || (a.ldr % 4 == 0 && ((uintptr_t)a.residual & 15) == 0))) {
+        const int wide = cdiv(a.J, 32);
+        const int mtiles = cdiv(a.I, BM), ksteps_total = cdiv(a.R, BK);
+        if (wide > wn && mtiles < 4 * ctx->num_cus) {
+            wn = wide;
+            int s = cdiv(2 * ctx->num_cus, mtiles);
+            if (s > ksteps_total / 4) s = ksteps_total / 4;
+            if (s >= 2) splits = s;
+        }
+    }
+    dim3 grid(cdiv(a.J, 32 * wn), splits > 1 ? cdiv(a.I, BM) : nparts, splits);
+    float* stats_out = a.stats;
+    if (splits > 1) {
+        void* ws;
+        int rc = ssdseg_workspace(ctx, (size_t)splits * a.I * a.J * sizeof(float), &ws);
+        if (rc) return rc;
+        a.kpart = (float*)ws;
+        a.ksteps = cdiv(cdiv(a.R, BK), splits);
+        a.stats = nullptr;
+    }
     size_t lds = (size_t)(BM * AS + BK * (32 * wn + 1)) * sizeof(float);
     size_t red = (size_t)(4 * 2 * 32 * wn) * sizeof(float);
     if (red > lds) lds = red;
@@ -637,6 +754,11 @@ int launch_rowA(ssdseg_ctx* ctx, const RowAArgs& a) {
         default: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<5, MODE, LD>), grid, dim3(256), lds, a); break;
     }
     SSDSEG_LAUNCH_CHECK();
+    if (splits > 1) {
+        SSDSEG_LAUNCH(ctx, 4.0 * ((double)splits + 1.0) * a.I * a.J, 0.0, splitk_reduce_kernel, dim3(nparts), dim3(256), 0, (const float*)a.kpart,
+                      splits, a.I, a.J, a.out, a.ldo, a.residual, a.ldr, a.accumulate, stats_out);
+        SSDSEG_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -787,7 +909,11 @@ int ssdseg_pwconv_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssd
     const bool force_fused = getenv("SSDSEG_PW_FUSED") != nullptr && getenv("SSDSEG_PW_FUSED")[0] == '1';
     const bool fused = k <= 32 && n <= 192 && (force_fused || (n > 32 && m >= 500000));
     if (!fused) {
+        // dW is off the critical path (nothing reads it before the optimizer): it runs on the side stream, concurrently with
+        // the backward-data GEMM and whatever follows it on the main stream
+        const bool side = ssdseg_side_begin(ctx);
         int rc = ssdseg_pwconv_bwd_weight(ctx, in, ldx, dy, ldy, dw, m, k, n);
+        if (side) ssdseg_side_end(ctx);
         if (rc) return rc;
         return ssdseg_pwconv_bwd_data(ctx, dy, ldy, w, dx, lddx, m, k, n, residual, ldr, accumulate);
     }

@@ -135,14 +135,26 @@ __global__ void __launch_bounds__(256) gemm_wres_kernel(RowAArgs p) {
             }
             const float* arow = As + li * AS + 4 * hh;
             const float* bcol = Ws + (kt * BK + 4 * hh) * BS + li;
+            // fragments one 8-deep group ahead of their MFMAs (two register sets), as in gemm_rowA_kernel
+            float4 afr[2];
+            float bfr[2][4][WN];
+            auto fetch = [&](int kk, int buf) {
+                afr[buf] = ld4(arow + kk * 8);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int nt = 0; nt < WN; ++nt) bfr[buf][jj][nt] = bcol[(kk * 8 + jj) * BS + nt * 32];
+            };
+            fetch(0, 0);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                const float4 a4 = ld4(arow + kk * 8);
-                const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+                if (kk + 1 < 4) fetch(kk + 1, (kk + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);   // keep the reads of group kk+1 in front of the MFMAs of group kk
+                const float av[4] = {afr[kk & 1].x, afr[kk & 1].y, afr[kk & 1].z, afr[kk & 1].w};
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
 #pragma unroll
-                    for (int nt = 0; nt < WN; ++nt) acc[nt] = mfma32(av[jj], bcol[(kk * 8 + jj) * BS + nt * 32], acc[nt]);
+                    for (int nt = 0; nt < WN; ++nt) acc[nt] = mfma32(av[jj], bfr[kk & 1][jj][nt], acc[nt]);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // all reads of the slab done before the next commit

@@ -3,6 +3,9 @@
 
 #include "common.h"
 
+#include <stdlib.h>
+#include <utility>
+
 static thread_local char g_err[512] = "";
 
 void ssdseg_set_error(const char* fmt, ...) {
@@ -197,6 +200,11 @@ int ssdseg_ctx_create(int device, void* stream, ssdseg_ctx** out_host) {
     c->num_cus = prop.multiProcessorCount;
     c->capturing = false;
     c->timing = nullptr;
+    c->side_stream = nullptr;
+    c->ev_fork = c->ev_join = nullptr;
+    c->side_workspace = nullptr;
+    c->side_workspace_bytes = 0;
+    c->side_ok = c->side_on = c->side_pending = false;
     if (stream) {
         c->stream = (hipStream_t)stream;
         c->owns_stream = false;
@@ -208,16 +216,58 @@ int ssdseg_ctx_create(int device, void* stream, ssdseg_ctx** out_host) {
         }
         c->owns_stream = true;
     }
+    // side stream (SSDSEG_NO_SIDE_STREAM=1 keeps everything on the one stream)
+    const char* noside = getenv("SSDSEG_NO_SIDE_STREAM");
+    if (!(noside && noside[0] == '1')) {
+        if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess)
+            c->side_ok = true;
+    }
     *out_host = c;
+    return 0;
+}
+
+bool ssdseg_side_begin(ssdseg_ctx* c) {
+    if (!c->side_ok || c->capturing || c->side_on) return false;
+    if (hipEventRecord(c->ev_fork, c->stream) != hipSuccess) return false;
+    if (hipStreamWaitEvent(c->side_stream, c->ev_fork, 0) != hipSuccess) return false;
+    std::swap(c->stream, c->side_stream);
+    std::swap(c->workspace, c->side_workspace);
+    std::swap(c->workspace_bytes, c->side_workspace_bytes);
+    c->side_on = true;
+    return true;
+}
+
+void ssdseg_side_end(ssdseg_ctx* c) {
+    if (!c->side_on) return;
+    std::swap(c->stream, c->side_stream);
+    std::swap(c->workspace, c->side_workspace);
+    std::swap(c->workspace_bytes, c->side_workspace_bytes);
+    c->side_on = false;
+    c->side_pending = true;
+}
+
+int ssdseg_join(ssdseg_ctx* c) {
+    if (c->side_on) ssdseg_side_end(c);
+    if (!c->side_pending) return 0;
+    SSDSEG_HIP(hipEventRecord(c->ev_join, c->side_stream));
+    SSDSEG_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    c->side_pending = false;
     return 0;
 }
 
 int ssdseg_ctx_destroy(ssdseg_ctx* ctx) {
     if (!ctx) return 0;
     (void)hipSetDevice(ctx->device);
+    (void)ssdseg_join(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     ssdseg_timing_enable(ctx, 0);
     if (ctx->workspace) (void)hipFree(ctx->workspace);
+    if (ctx->side_workspace) (void)hipFree(ctx->side_workspace);
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
@@ -225,8 +275,15 @@ int ssdseg_ctx_destroy(ssdseg_ctx* ctx) {
 
 int ssdseg_ctx_sync(ssdseg_ctx* ctx) {
     SSDSEG_ARG(ctx != nullptr, 1);
+    int rc = ssdseg_join(ctx);
+    if (rc) return rc;
     SSDSEG_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
+}
+
+int ssdseg_ctx_join(ssdseg_ctx* ctx) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    return ssdseg_join(ctx);
 }
 
 int ssdseg_ctx_reserve(ssdseg_ctx* ctx, size_t workspace_bytes) {
@@ -265,6 +322,7 @@ int ssdseg_memcpy_h2d(ssdseg_ctx* ctx, void* dst, const void* src_host, size_t b
     if (bytes == 0) return 0;
     SSDSEG_ARG(dst != nullptr, 2);
     SSDSEG_ARG(src_host != nullptr, 3);
+    { int jrc = ssdseg_join(ctx); if (jrc) return jrc; }
     SSDSEG_HIP(hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
     SSDSEG_HIP(hipStreamSynchronize(ctx->stream));  // pageable host memory: the caller may reuse it
     return 0;
@@ -275,6 +333,7 @@ int ssdseg_memcpy_d2h(ssdseg_ctx* ctx, void* dst_host, const void* src, size_t b
     if (bytes == 0) return 0;
     SSDSEG_ARG(dst_host != nullptr, 2);
     SSDSEG_ARG(src != nullptr, 3);
+    { int jrc = ssdseg_join(ctx); if (jrc) return jrc; }
     SSDSEG_HIP(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     SSDSEG_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
@@ -285,6 +344,7 @@ int ssdseg_memcpy_d2d(ssdseg_ctx* ctx, void* dst, const void* src, size_t bytes)
     if (bytes == 0) return 0;
     SSDSEG_ARG(dst != nullptr, 2);
     SSDSEG_ARG(src != nullptr, 3);
+    { int jrc = ssdseg_join(ctx); if (jrc) return jrc; }
     SSDSEG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return 0;
 }
@@ -293,6 +353,7 @@ int ssdseg_memset(ssdseg_ctx* ctx, void* dst, int value, size_t bytes) {
     SSDSEG_ARG(ctx != nullptr, 1);
     if (bytes == 0) return 0;
     SSDSEG_ARG(dst != nullptr, 2);
+    { int jrc = ssdseg_join(ctx); if (jrc) return jrc; }
     SSDSEG_HIP(hipMemsetAsync(dst, value, bytes, ctx->stream));
     return 0;
 }
@@ -315,6 +376,7 @@ int ssdseg_event_destroy(ssdseg_ctx* ctx, void* ev) {
 int ssdseg_event_record(ssdseg_ctx* ctx, void* ev) {
     SSDSEG_ARG(ctx != nullptr, 1);
     SSDSEG_ARG(ev != nullptr, 2);
+    { int jrc = ssdseg_join(ctx); if (jrc) return jrc; }
     SSDSEG_HIP(hipEventRecord((hipEvent_t)ev, ctx->stream));
     return 0;
 }
@@ -332,6 +394,7 @@ int ssdseg_event_elapsed_ms(ssdseg_ctx* ctx, void* ev_start, void* ev_stop, floa
 int ssdseg_graph_begin(ssdseg_ctx* ctx) {
     SSDSEG_ARG(ctx != nullptr, 1);
     SSDSEG_ARG(!ctx->capturing, 1);
+    { int jrc = ssdseg_join(ctx); if (jrc) return jrc; }
     SSDSEG_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
     ctx->capturing = true;
     return 0;

@@ -904,6 +904,7 @@ class Engine:
                 s.gwritten = True
         for op in reversed(self.ops):
             op.bwd()
+        self.ctx.join()     # weight-gradient kernels on the side stream: done before anyone (optimizer, all-reduce) reads them
 
     def seed_output_grad(self, index: int, g):
         """inject dL/d(output[index]) (bench config 2 / tests): output values are the ACTIVATED tensors"""
@@ -924,6 +925,7 @@ class Engine:
         self.mark_output_grads_written()
         for op in reversed(self.ops):
             op.bwd()
+        self.ctx.join()
 
     def output(self, index: int) -> np.ndarray:
         """activated value of output `index` as a NumPy array (N, H, W, C) -- for tests / predict"""

@@ -42,6 +42,7 @@ _SIGNATURES = {
     "ssdseg_ctx_create": [_i, _vp, C.POINTER(_vp)],
     "ssdseg_ctx_destroy": [_vp],
     "ssdseg_ctx_sync": [_vp],
+    "ssdseg_ctx_join": [_vp],
     "ssdseg_ctx_reserve": [_vp, _sz],
     "ssdseg_ctx_device_name": [_vp, C.c_char_p, _sz],
     "ssdseg_malloc": [_vp, _sz, C.POINTER(_vp)],
@@ -286,6 +287,10 @@ class Context:
 
     def sync(self):
         _check(self.lib.ssdseg_ctx_sync(self.handle), "ssdseg_ctx_sync")
+
+    def join(self):
+        """main stream waits for the side-stream work queued so far (weight gradients)"""
+        _check(self.lib.ssdseg_ctx_join(self.handle), "ssdseg_ctx_join")
 
     def reserve(self, nbytes: int):
         _check(self.lib.ssdseg_ctx_reserve(self.handle, int(nbytes)), "ssdseg_ctx_reserve")

@@ -20,6 +20,7 @@ KERNEL_FAMILIES = {
     "general": {"SSDSEG_NO_WRES": "1", "SSDSEG_DW_FWD": "lds", "SSDSEG_DW_BWD": "lds"},
     "general-reg": {"SSDSEG_NO_WRES": "1", "SSDSEG_DW_FWD": "lds", "SSDSEG_DW_BWD": "reg"},
     "resident-fused": {"SSDSEG_WRES_FORCE": "1", "SSDSEG_PW_FUSED": "1"},
+    "split-k": {"SSDSEG_NO_WRES": "1", "SSDSEG_SPLITK": "1"},
 }
 
 
@@ -49,7 +50,7 @@ def rng():
 
 @pytest.fixture(params=list(KERNEL_FAMILIES))
 def kernel_family(request, monkeypatch):
-    for k in ("SSDSEG_NO_WRES", "SSDSEG_WRES_FORCE", "SSDSEG_PW_FUSED", "SSDSEG_DW_FWD", "SSDSEG_DW_BWD"):
+    for k in ("SSDSEG_NO_WRES", "SSDSEG_WRES_FORCE", "SSDSEG_PW_FUSED", "SSDSEG_DW_FWD", "SSDSEG_DW_BWD", "SSDSEG_SPLITK"):
         monkeypatch.delenv(k, raising=False)
     for k, v in KERNEL_FAMILIES[request.param].items():
         monkeypatch.setenv(k, v)

@@ -133,6 +133,8 @@ PW_CASES = [
     (77, 360, 24),
     (4096, 32, 16),
     (100, 8, 4),
+    (1500, 64, 384),     # backward-data with a long reduction and few row tiles: wide tile + split-K (+ residual, accumulate)
+    (1500, 960, 160),    # forward the same way (BN statistics come from the split-K reduce kernel)
     (70001, 24, 144),    # fused dx+dW kernel: more row tiles than blocks, ragged last tile, 4.5 column chunks
     (66000, 32, 192),    # fused, 6 chunks (largest shape the fused kernel takes)
 ]
