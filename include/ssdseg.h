@@ -87,6 +87,9 @@ int ssdseg_ctx_sync(ssdseg_ctx* ctx);
  * that synchronises, copies, records an event or runs the optimizer joins it implicitly; a caller that hands the gradient
  * buffers to ANOTHER library on the ctx stream (the RCCL all-reduce of torch.distributed) calls this first. */
 int ssdseg_ctx_join(ssdseg_ctx* ctx);
+/* on != 0: the launches that follow go to the side stream (after everything queued so far); on == 0: back to the ctx stream.
+ * For callers that issue a weight-gradient entry point themselves (ssdseg_pwconv_bwd does this internally). */
+int ssdseg_ctx_side(ssdseg_ctx* ctx, int on);
 int ssdseg_ctx_reserve(ssdseg_ctx* ctx, size_t workspace_bytes);
 int ssdseg_ctx_device_name(ssdseg_ctx* ctx, char* buf_host, size_t buf_len);
 int ssdseg_malloc(ssdseg_ctx* ctx, size_t bytes, void** out_host);

@@ -286,6 +286,13 @@ int ssdseg_ctx_join(ssdseg_ctx* ctx) {
     return ssdseg_join(ctx);
 }
 
+int ssdseg_ctx_side(ssdseg_ctx* ctx, int on) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    if (on) (void)ssdseg_side_begin(ctx);
+    else ssdseg_side_end(ctx);
+    return 0;
+}
+
 int ssdseg_ctx_reserve(ssdseg_ctx* ctx, size_t workspace_bytes) {
     SSDSEG_ARG(ctx != nullptr, 1);
     void* p;

@@ -242,7 +242,11 @@ class Conv3Op(Op):
     def bwd(self):
         s = self.inp.store
         gv = self.out_val.gview()
-        self.e.ctx.call("ssdseg_conv3x3_bwd_weight", self.inp.view(), s.ld, gv, self.dw, s.n, s.h, s.w, s.c, self.out.c)
+        self.e.ctx.side(True)      # dW is off the critical path: side stream, concurrent with the backward-data conv
+        try:
+            self.e.ctx.call("ssdseg_conv3x3_bwd_weight", self.inp.view(), s.ld, gv, self.dw, s.n, s.h, s.w, s.c, self.out.c)
+        finally:
+            self.e.ctx.side(False)
         if s.need_grad:
             dx, acc = s.grad_slot()
             self.e.ctx.call("ssdseg_conv3x3_bwd_data", gv, self.w, dx, s.ld, s.n, s.h, s.w, s.c, self.out.c, acc)
