@@ -906,8 +906,9 @@ int ssdseg_pwconv_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssd
     // loses with a single 32-column chunk, where the per-tile set-up dominates.  Its 16*NT accumulator registers cap the
     // occupancy at 1-2 waves per SIMD, which is why it stops at ~3.4 TB/s.  SSDSEG_PW_FUSED=1 forces it for every shape it
     // supports (k <= 32, n <= 192); the parity tests run both ways.
-    const bool force_fused = getenv("SSDSEG_PW_FUSED") != nullptr && getenv("SSDSEG_PW_FUSED")[0] == '1';
-    const bool fused = k <= 32 && n <= 192 && (force_fused || (n > 32 && m >= 500000));
+    const char* fenv = getenv("SSDSEG_PW_FUSED");   // "1": every supported shape, "0": never, unset: where it measured faster
+    const bool force_fused = fenv != nullptr && fenv[0] == '1', never_fused = fenv != nullptr && fenv[0] == '0';
+    const bool fused = !never_fused && k <= 32 && n <= 192 && (force_fused || (n > 32 && m >= 500000));
     if (!fused) {
         // dW is off the critical path (nothing reads it before the optimizer): it runs on the side stream, concurrently with
         // the backward-data GEMM and whatever follows it on the main stream

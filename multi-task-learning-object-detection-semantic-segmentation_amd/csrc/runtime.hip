@@ -209,7 +209,10 @@ int ssdseg_ctx_create(int device, void* stream, ssdseg_ctx** out_host) {
         c->stream = (hipStream_t)stream;
         c->owns_stream = false;
     } else {
-        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        // highest priority: the main stream carries the critical path; side-stream work (lowest priority) fills the gaps
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        hipError_t e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi);
         if (e != hipSuccess) {
             delete c;
             return ssdseg_hip_fail(e, "hipStreamCreateWithFlags");
@@ -219,7 +222,9 @@ int ssdseg_ctx_create(int device, void* stream, ssdseg_ctx** out_host) {
     // side stream (SSDSEG_NO_SIDE_STREAM=1 keeps everything on the one stream)
     const char* noside = getenv("SSDSEG_NO_SIDE_STREAM");
     if (!(noside && noside[0] == '1')) {
-        if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) == hipSuccess &&
+        int plo = 0, phi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
+        if (hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, plo) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess)
             c->side_ok = true;
