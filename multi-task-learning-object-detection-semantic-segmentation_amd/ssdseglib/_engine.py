@@ -57,6 +57,7 @@ class Store:
         self.need_grad = need_grad
         self._grad: Optional[H.DeviceBuffer] = None
         self.gwritten = False
+        self.pending = None        # (buffer, ld): deferred residual contribution to this gradient (see defer_residual)
         self.split_parent = False  # channel Split views write disjoint ranges of this gradient: zero it, then everyone accumulates
         self.stats: Optional[H.DeviceBuffer] = None   # per-block (sum, sumsq) partials from the producing conv
         self.nparts = 0
@@ -68,21 +69,56 @@ class Store:
         self.eng.stores.append(child)      # so its "gradient written" flag is reset with everyone else's each backward pass
         return child
 
-    @property
-    def grad(self) -> H.DeviceBuffer:
+    def _raw_grad(self) -> H.DeviceBuffer:
         if self._grad is None:
             if self.parent is not None:
-                pg = self.parent.grad
+                pg = self.parent._raw_grad()
                 self._grad = pg.view(self.coff, (self.m * self.ld - self.coff,))
             else:
                 self._grad = self.eng.ctx.zeros((self.m, self.ld))
         return self._grad
 
+    @property
+    def grad(self) -> H.DeviceBuffer:
+        """the gradient buffer, complete as far as the backward pass has come (a deferred residual contribution is added first)"""
+        self._materialise_pending()
+        return self._raw_grad()
+
+    def _written(self) -> bool:
+        return self.gwritten or (self.parent is not None and self.parent.gwritten)
+
+    def _materialise_pending(self):
+        if self.pending is not None:
+            buf, ld = self.pending
+            self.pending = None
+            self.eng.ctx.call("ssdseg_axpby", buf, ld, self._raw_grad(), self.ld, self.m, self.c, 1.0, 1.0 if self._written() else 0.0)
+            self.gwritten = True
+
+    def defer_residual(self, buf: H.DeviceBuffer, ld: int) -> bool:
+        """Residual-Add backward: instead of copying the Add's output gradient into this (block input) gradient now, let the
+        next writer -- the expand conv's backward-data GEMM -- add it in its epilogue.  False: not possible, copy as usual."""
+        if self.parent is not None or self._written() or self.pending is not None or self.split_parent:
+            return False
+        self.pending = (buf, ld)
+        return True
+
     def grad_slot(self) -> Tuple[H.DeviceBuffer, int]:
         """(gradient buffer, accumulate flag) for a consumer's backward; first writer overwrites."""
-        acc = 1 if (self.gwritten or (self.parent is not None and self.parent.gwritten)) else 0
+        self._materialise_pending()
+        acc = 1 if self._written() else 0
         self.gwritten = True
-        return self.grad, acc
+        return self._raw_grad(), acc
+
+    def grad_slot_residual(self):
+        """as grad_slot for a writer whose kernel can add a residual tensor itself: (buffer, accumulate, residual, ldr)"""
+        res, ldr = (None, 0)
+        if self.pending is not None and not self._written():
+            (res, ldr), self.pending = self.pending, None
+        else:
+            self._materialise_pending()
+        acc = 1 if self._written() else 0
+        self.gwritten = True
+        return self._raw_grad(), acc, res, ldr
 
 
 class BNRec:
@@ -216,9 +252,9 @@ class PwOp(Op):
         gv = self.out_val.gview()
         if s.need_grad:
             # dx and dW in one call: for few input channels (the expand convs) one kernel reads the wide gradient once
-            dx, acc = s.grad_slot()
+            dx, acc, res, ldr = s.grad_slot_residual()
             self.e.ctx.call("ssdseg_pwconv_bwd", self.inp.view(), s.ld, gv, self.out.ld, self.w, dx, s.ld, self.dw, self.m, self.k, self.n,
-                            None, 0, acc)
+                            res, ldr, acc)
         else:
             self.e.ctx.call("ssdseg_pwconv_bwd_weight", self.inp.view(), s.ld, gv, self.out.ld, self.dw, self.m, self.k, self.n)
 
@@ -301,14 +337,22 @@ class ApplyOp(Op):
         self.e.ctx.call("ssdseg_bn_apply", a.view(), a.store.ld, b.view() if b is not None else None, b.store.ld if b is not None else 0,
                         o.buf, o.ld, o.m, o.c)
 
+    alias_a = False   # Add: `a` (a projection's BN output consumed only here) shares this op's output-gradient buffer
+
     def bwd(self):
         o = self.out
+        og = o.grad
         for v in (self.a, self.b):
             if v is None or not v.store.need_grad:
                 continue
             # d(out)/d(activated value) = 1 (the activation mask is applied by the producer's BN/ReLU backward)
+            if v is self.a and self.alias_a:
+                v.store.gwritten = True            # dL/da IS dL/dout: same buffer, no copy
+                continue
+            if v is self.b and self.b is not None and v.store.defer_residual(og, o.ld):
+                continue                           # added by the next writer's GEMM epilogue (or on first read)
             g, acc = v.store.grad_slot()
-            self.e.ctx.call("ssdseg_axpby", o.grad, o.ld, g, v.store.ld, o.m, o.c, 1.0, 1.0 if acc else 0.0)
+            self.e.ctx.call("ssdseg_axpby", og, o.ld, g, v.store.ld, o.m, o.c, 1.0, 1.0 if acc else 0.0)
 
 
 class ActBwdOp(Op):
@@ -729,7 +773,12 @@ class Engine:
             setv(nv)
         elif isinstance(layer, K.Add):
             st = self._out_store(layer, out_t.shape)
-            self._emit(ApplyOp(self, ins[1], ins[0], st, layer.name))
+            op = self._emit(ApplyOp(self, ins[1], ins[0], st, layer.name))
+            a = ins[1]
+            if (self.training and a.bn is not None and a.store.parent is None and st.parent is None and a.store.ld == st.ld and a.store.c == st.c
+                    and len(self.cons.get(id(layer.inbound[1]), [])) == 1 and id(layer.inbound[1]) not in {id(t) for t in self.model.outputs}):
+                a.store._grad = st._raw_grad()    # dL/d(projection output) == dL/d(Add output): one buffer
+                op.alias_a = True
             setv(Val(st))
         elif isinstance(layer, K.Concatenate):
             self._lower_concat(layer, ins, setv)
@@ -908,6 +957,8 @@ class Engine:
                 s.gwritten = True
         for op in reversed(self.ops):
             op.bwd()
+        for s in self.stores:
+            s._materialise_pending()
         self.ctx.join()     # weight-gradient kernels on the side stream: done before anyone (optimizer, all-reduce) reads them
 
     def seed_output_grad(self, index: int, g):
@@ -929,6 +980,8 @@ class Engine:
         self.mark_output_grads_written()
         for op in reversed(self.ops):
             op.bwd()
+        for s in self.stores:
+            s._materialise_pending()
         self.ctx.join()
 
     def output(self, index: int) -> np.ndarray:
