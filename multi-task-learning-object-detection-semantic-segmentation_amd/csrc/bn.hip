@@ -7,10 +7,10 @@ namespace {
 
 constexpr int MAX_PARTS = 1024;
 
-// Partial-row reductions: blocks of RC channels x RP lanes along the partial rows (RC * RP == 1024).  A table with many
+// Partial-row reductions: blocks of RC channels x RP lanes along the partial rows (RC * RP == RTHREADS).  A table with many
 // rows and few channels (BN partials of a 16..160-channel tensor: up to 2048 rows) would otherwise run on c/32 blocks with
 // 64 dependent loads per thread; the narrow shape gives 4x the blocks and 4x fewer serial loads.
-constexpr int RTHREADS = 1024;
+constexpr int RTHREADS = 256;   // small blocks: they have to find room next to the side stream's GEMM blocks
 
 // Sums part[p][v][ch] over p for v < NV: RP lanes along p per channel, 4 independent fp64 chains per lane, then a fixed-
 // order fold (deterministic).  Result valid for threadIdx.y == 0.  red: NV * RP * (RC + 1) doubles of LDS.
@@ -66,8 +66,8 @@ __device__ __forceinline__ void reduce_parts(const float* __restrict__ part, int
 // channels per block for a table of nparts rows
 // (narrow blocks read 32-byte row segments, so they are only worth it while the table is too narrow to fill the chip)
 inline int reduce_rc(int nparts, long long len) {
-    if (nparts < 32) return 128;
-    return (nparts >= 256 && len < 2048) ? 8 : 32;
+    if (nparts < 32) return 32;
+    return (nparts >= 256 && len < 2048) ? 2 : 8;
 }
 
 template <int RC>
@@ -272,9 +272,9 @@ int ssdseg_bn_bwd_finalize_launch(ssdseg_ctx* ctx, const float* part, int nparts
 #define SSDSEG_BNBF(RCV)                                                                                                              \
     SSDSEG_LAUNCH_NAMED(ctx, "bn_bwd_finalize_kernel", 8.0 * nparts * c, 0.0, bn_bwd_finalize_kernel<RCV>, fgrid, fblock, 0, part, nparts, c, \
                         count, scale, mean, invstd, dgamma, dbeta, k1, k0)
-    if (rcw == 8) SSDSEG_BNBF(8);
-    else if (rcw == 32) SSDSEG_BNBF(32);
-    else SSDSEG_BNBF(128);
+    if (rcw == 2) SSDSEG_BNBF(2);
+    else if (rcw == 8) SSDSEG_BNBF(8);
+    else SSDSEG_BNBF(32);
 #undef SSDSEG_BNBF
     SSDSEG_LAUNCH_CHECK();
     return 0;
@@ -283,9 +283,9 @@ int ssdseg_bn_bwd_finalize_launch(ssdseg_ctx* ctx, const float* part, int nparts
 int ssdseg_colsum(ssdseg_ctx* ctx, const float* part, int nparts, long long len, float* out) {
     const int rc = reduce_rc(nparts, len);
     const dim3 grid(cdiv(len, rc)), block(rc, RTHREADS / rc);
-    if (rc == 8) SSDSEG_LAUNCH_NAMED(ctx, "colsum_kernel", 4.0 * nparts * len, 0.0, colsum_kernel<8>, grid, block, 0, part, nparts, (int)len, out);
-    else if (rc == 32) SSDSEG_LAUNCH_NAMED(ctx, "colsum_kernel", 4.0 * nparts * len, 0.0, colsum_kernel<32>, grid, block, 0, part, nparts, (int)len, out);
-    else SSDSEG_LAUNCH_NAMED(ctx, "colsum_kernel", 4.0 * nparts * len, 0.0, colsum_kernel<128>, grid, block, 0, part, nparts, (int)len, out);
+    if (rc == 2) SSDSEG_LAUNCH_NAMED(ctx, "colsum_kernel", 4.0 * nparts * len, 0.0, colsum_kernel<2>, grid, block, 0, part, nparts, (int)len, out);
+    else if (rc == 8) SSDSEG_LAUNCH_NAMED(ctx, "colsum_kernel", 4.0 * nparts * len, 0.0, colsum_kernel<8>, grid, block, 0, part, nparts, (int)len, out);
+    else SSDSEG_LAUNCH_NAMED(ctx, "colsum_kernel", 4.0 * nparts * len, 0.0, colsum_kernel<32>, grid, block, 0, part, nparts, (int)len, out);
     SSDSEG_LAUNCH_CHECK();
     return 0;
 }
@@ -305,14 +305,14 @@ int ssdseg_bn_finalize(ssdseg_ctx* ctx, const float* stats, int nparts, int c, d
     SSDSEG_ARG((moving_mean == nullptr) == (moving_var == nullptr), 11);
     SSDSEG_ARG(scale != nullptr, 14);
     SSDSEG_ARG(shift != nullptr, 15);
-    const int rc = training ? reduce_rc(nparts, c) : 128;
+    const int rc = training ? reduce_rc(nparts, c) : 32;
     const dim3 grid(cdiv(c, rc)), block(rc, RTHREADS / rc);
 #define SSDSEG_BNF(RCV)                                                                                                                     \
     SSDSEG_LAUNCH_NAMED(ctx, "bn_finalize_kernel", 8.0 * nparts * c, 0.0, bn_finalize_kernel<RCV>, grid, block, 0, stats, nparts, c, count, gamma, \
                         beta, eps, momentum, moving_mean, moving_var, mean, invstd, scale, shift, training)
-    if (rc == 8) SSDSEG_BNF(8);
-    else if (rc == 32) SSDSEG_BNF(32);
-    else SSDSEG_BNF(128);
+    if (rc == 2) SSDSEG_BNF(2);
+    else if (rc == 8) SSDSEG_BNF(8);
+    else SSDSEG_BNF(32);
 #undef SSDSEG_BNF
     SSDSEG_LAUNCH_CHECK();
     return 0;
