@@ -170,6 +170,12 @@ int ssdseg_pwconv_bwd_weight(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, co
 int ssdseg_pwconv_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssdseg_gview* dy, int ldy, const float* w,
                       float* dx, int lddx, float* dw, int m, int k, int n, const float* residual, int ldr,
                       int accumulate);
+/* dx + dw plus the BatchNormalization backward of the layer that FEEDS this conv (in is that BN's view, models.py:89-90 ->
+ * :110): the backward-data kernel's float4 epilogue reduces sum(mask*dx) and sum(mask*dx*xhat) while it stores dx.  Only
+ * valid when this conv is the ONLY consumer of the BN output.  Outputs as ssdseg_bn_bwd_reduce (dgamma, dbeta may be NULL). */
+int ssdseg_pwconv_bwd_bn(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssdseg_gview* dy, int ldy, const float* w,
+                         float* dx, int lddx, float* dw, int m, int k, int n, const float* in_mean,
+                         const float* in_invstd, float* in_dgamma, float* in_dbeta, float* in_k1, float* in_k0);
 
 /* ---------------------------------------------------------------- K6: dense 3x3 stride 1 SAME (implicit GEMM)
  * Conv2D 3x3 in the DeepLabV3+ decoder (blocks.py:117,127).  w: [3][3][cin][cout]. */

@@ -17,6 +17,9 @@
 
 #include <stdlib.h>
 
+// bn.hip: (dgamma, dbeta, k1, k0) from nparts partial rows of (sum mask*g, sum mask*g*xhat)
+int ssdseg_bn_bwd_finalize_launch(ssdseg_ctx* ctx, const float* part, int nparts, int c, double count, const float* scale,
+                                  const float* mean, const float* invstd, float* dgamma, float* dbeta, float* k1, float* k0);
 int ssdseg_colsum(ssdseg_ctx* ctx, const float* part, int nparts, long long len, float* out);
 
 namespace {
@@ -63,6 +66,16 @@ struct RowAArgs {
     // kpart[z][I][J]; bias / residual / accumulate / statistics then belong to splitk_reduce_kernel
     int ksteps;
     float* kpart;
+    // BNE (MODE 1): BatchNorm backward of the producer of this conv's INPUT, fused into the (LDS-transposed, float4) epilogue:
+    // raw input bn_y[I][J] (ld ldby), that BN's scale/shift/mean/invstd/activation; bnpart: [gridDim.y][2][J] partial rows of
+    // (sum mask*dx, sum mask*dx*xhat)
+    const float* bn_y;
+    const float* bn_s;
+    const float* bn_t;
+    const float* bn_mean;
+    const float* bn_istd;
+    int bn_act, ldby;
+    float* bnpart;
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -73,9 +86,14 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 // NT > 0 (MODE 1, LD 0, WN 1, J <= 32, R <= 32*NT): fused backward of a pointwise conv with few input channels (the MBConv
 // expand convs): the same pass over (g, y) that yields dx = dy * W^T also accumulates dW = a^T * dy, one 32x32 tile per
 // 32-column chunk of dy, each wave over its own 32 rows -- so the 6x-wide gradient is read once instead of twice.
-template <int WN, int MODE, int LD, int NT = 0>
+// BNE (MODE 1, LD 0, NT 0): float4 epilogue through LDS -- the 128 x BN tile leaves the accumulators in two 64-row halves,
+// is re-read as rows of float4 (thread = fixed float4 column, several rows), added to residual / previous contents, stored
+// with 16-byte lanes, and in the same pass reduced into the BatchNorm-backward sums of the layer that produced this conv's
+// input (one extra read of that layer's raw output instead of a separate two-tensor reduction pass).
+template <int WN, int MODE, int LD, int NT = 0, bool BNE = false>
 __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
     constexpr bool CONV = LD == 1, STEM = LD == 2, FUSEW = NT > 0;
+    static_assert(!BNE || (MODE == 1 && LD == 0 && NT == 0), "BN epilogue only for plain backward-data");
     static_assert(!FUSEW || (MODE == 1 && LD == 0 && WN == 1), "fused dW only for plain backward-data with one column tile");
     constexpr int BN = 32 * WN;
     constexpr int BS = BN + 1;
@@ -198,6 +216,13 @@ __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) wacc[q][e] = 0.f;
     float xop[FUSEW ? 16 : 1];     // FUSEW: A operand a[m0 + 32*wave + 2s + hh][j = li] of the dW products, per row tile
+    // BNE: this thread's float4 column of the epilogue and its BatchNorm constants / running sums
+    float4 ebs = f4(0.f), ebt = f4(0.f), ebm = f4(0.f), ebi = f4(0.f), esb = f4(0.f), esg = f4(0.f);
+    const float bnlo = act_lo(p.bn_act), bnhi = act_hi(p.bn_act);
+    if (BNE) {
+        const int ec4 = t % (BN / 4), ej = j0 + ec4 * 4;
+        if (ej < p.J) { ebs = ld4(p.bn_s + ej); ebt = ld4(p.bn_t + ej); ebm = ld4(p.bn_mean + ej); ebi = ld4(p.bn_istd + ej); }
+    }
 
     // a block walks row tiles blockIdx.y, blockIdx.y + gridDim.y, ... so the number of BN partial rows stays small
     for (int mt = blockIdx.y; mt < mtiles; mt += gridDim.y) {
@@ -291,6 +316,54 @@ __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
         for (int e = 0; e < 16; ++e) acc[0][e] += accb[e];
     }
 
+    if (BNE) {
+        constexpr int CS = BN + 4;        // LDS row stride of the transposed tile (float4-aligned)
+        constexpr int CV = BN / 4;        // float4 columns
+        constexpr int RPP = 256 / CV;     // rows per pass of the 256 threads
+        float* Cs = smem;                 // [64][CS], over As/Bs (all waves are past their last operand read after the barrier)
+        const int er = t / CV, ec4 = t - er * CV;
+        const int ej = j0 + ec4 * 4;
+        const bool eact = er < RPP && ej < p.J;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            __syncthreads();
+            if ((wave >> 1) == h) {
+#pragma unroll
+                for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        Cs[((wave & 1) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh) * CS + nt * 32 + li] = acc[nt][e];
+            }
+            __syncthreads();
+            if (eact) {
+                for (int row = er; row < 64; row += RPP) {
+                    const int m = m0 + h * 64 + row;
+                    if (m >= p.I) break;
+                    float4 v = ld4(Cs + row * CS + ec4 * 4);
+                    if (p.residual) {
+                        const float4 r4 = ld4(p.residual + (long long)m * p.ldr + ej);
+                        v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+                    }
+                    float* o = p.out + (long long)m * p.ldo + ej;
+                    if (p.accumulate) {
+                        const float4 o4 = ld4(o);
+                        v.x += o4.x; v.y += o4.y; v.z += o4.z; v.w += o4.w;
+                    }
+                    st4(o, v);
+                    const float4 yv = ld4(p.bn_y + (long long)m * p.ldby + ej);
+                    float4 mg;
+                    mg.x = (fmaf(ebs.x, yv.x, ebt.x) > bnlo && fmaf(ebs.x, yv.x, ebt.x) < bnhi) ? v.x : 0.f;
+                    mg.y = (fmaf(ebs.y, yv.y, ebt.y) > bnlo && fmaf(ebs.y, yv.y, ebt.y) < bnhi) ? v.y : 0.f;
+                    mg.z = (fmaf(ebs.z, yv.z, ebt.z) > bnlo && fmaf(ebs.z, yv.z, ebt.z) < bnhi) ? v.z : 0.f;
+                    mg.w = (fmaf(ebs.w, yv.w, ebt.w) > bnlo && fmaf(ebs.w, yv.w, ebt.w) < bnhi) ? v.w : 0.f;
+                    esb.x += mg.x; esb.y += mg.y; esb.z += mg.z; esb.w += mg.w;
+                    esg.x = fmaf(mg.x, (yv.x - ebm.x) * ebi.x, esg.x); esg.y = fmaf(mg.y, (yv.y - ebm.y) * ebi.y, esg.y);
+                    esg.z = fmaf(mg.z, (yv.z - ebm.z) * ebi.z, esg.z); esg.w = fmaf(mg.w, (yv.w - ebm.w) * ebi.w, esg.w);
+                }
+            }
+        }
+        __syncthreads();   // the tile is consumed: the next row tile may overwrite As/Bs
+    } else {
     // ---------------- epilogue: C/D layout col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
 #pragma unroll
     for (int nt = 0; nt < WN; ++nt) {
@@ -315,6 +388,7 @@ __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
             }
         }
     }
+    }   // !BNE
     if (MODE == 0 && p.stats != nullptr) {
         // per-channel (sum, sumsq) of this 128-row tile; padded rows are exactly zero
 #pragma unroll
@@ -349,6 +423,25 @@ __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
         }
     }
 
+    if (BNE) {
+        // fold the threads that share a float4 column (fixed order) -> this block's partial row
+        constexpr int CV = BN / 4, RPP = 256 / CV;
+        float4* red4 = reinterpret_cast<float4*>(smem);   // [2][256]
+        __syncthreads();
+        red4[t] = esb;
+        red4[256 + t] = esg;
+        __syncthreads();
+        if (t < CV && j0 + t * 4 < p.J) {
+            float4 a = f4(0.f), b = f4(0.f);
+            for (int k = 0; k < RPP; ++k) {
+                const float4 x = red4[k * CV + t], y = red4[256 + k * CV + t];
+                a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+                b.x += y.x; b.y += y.y; b.z += y.z; b.w += y.w;
+            }
+            st4(p.bnpart + ((long long)blockIdx.y * 2 + 0) * p.J + j0 + t * 4, a);
+            st4(p.bnpart + ((long long)blockIdx.y * 2 + 1) * p.J + j0 + t * 4, b);
+        }
+    }
     if (MODE == 0 && p.stats != nullptr) {
         __syncthreads();
         float* red = smem;  // [4 waves][2][BN]
@@ -976,6 +1069,73 @@ int ssdseg_pwconv_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssd
         return 0;
     }
     return ssdseg_colsum(ctx, a.wpart, gy, (long long)k * n, dw);
+}
+
+// dx + dW of a pointwise conv plus the BatchNorm backward of the layer feeding it (the depthwise BN in front of a project conv):
+// the backward-data kernel's float4 epilogue reduces sum(mask*dx), sum(mask*dx*xhat) while it stores dx.  Only valid when this
+// conv is the ONLY consumer of that BatchNorm's output.  Falls back to the separate reduction pass for unaligned tensors.
+int ssdseg_pwconv_bwd_bn(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssdseg_gview* dy, int ldy, const float* w, float* dx,
+                         int lddx, float* dw, int m, int k, int n, const float* in_mean, const float* in_invstd, float* in_dgamma,
+                         float* in_dbeta, float* in_k1, float* in_k0) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(in != nullptr && in->x != nullptr && in->scale != nullptr && in->shift != nullptr, 2);
+    SSDSEG_ARG(ldx >= k && ldx % 4 == 0, 3);
+    SSDSEG_ARG(dy != nullptr && dy->g != nullptr, 4);
+    SSDSEG_ARG(dy->scale == nullptr || (dy->y && dy->shift && dy->k1 && dy->k0), 4);
+    SSDSEG_ARG(ldy >= n && ldy % 4 == 0, 5);
+    SSDSEG_ARG(w != nullptr, 6);
+    SSDSEG_ARG(dx != nullptr, 7);
+    SSDSEG_ARG(lddx >= k, 8);
+    SSDSEG_ARG(dw != nullptr, 9);
+    SSDSEG_ARG(m > 0, 10);
+    SSDSEG_ARG(k > 0 && k % 4 == 0, 11);
+    SSDSEG_ARG(n > 0 && n % 4 == 0, 12);
+    SSDSEG_ARG(in_mean != nullptr && in_invstd != nullptr, 13);
+    SSDSEG_ARG(in_k1 != nullptr && in_k0 != nullptr, 17);
+    // dW first, on the side stream (it only reads)
+    const bool side = ssdseg_side_begin(ctx);
+    int rc = ssdseg_pwconv_bwd_weight(ctx, in, ldx, dy, ldy, dw, m, k, n);
+    if (side) ssdseg_side_end(ctx);
+    if (rc) return rc;
+    const bool aligned = lddx % 4 == 0 && ((uintptr_t)dx & 15) == 0 && ((uintptr_t)in->x & 15) == 0;
+    const char* benv = getenv("SSDSEG_NO_BN_EPILOGUE");
+    if (!aligned || (benv != nullptr && benv[0] == '1')) {
+        rc = ssdseg_pwconv_bwd_data(ctx, dy, ldy, w, dx, lddx, m, k, n, nullptr, 0, 0);
+        if (rc) return rc;
+        return ssdseg_bn_bwd_reduce(ctx, dx, lddx, in->x, ldx, m, k, in->scale, in->shift, in_mean, in_invstd, in->act, in_dgamma, in_dbeta,
+                                    in_k1, in_k0);
+    }
+    RowAArgs a{};
+    a.a0 = dy->g; a.a1 = dy->y; a.cs = dy->scale; a.ct = dy->shift; a.ck1 = dy->k1; a.ck0 = dy->k0; a.act = dy->act;
+    a.lda = ldy;
+    a.b = w; a.ldb = n;
+    a.out = dx; a.ldo = lddx;
+    a.I = m; a.R = n; a.J = k;
+    const int wn = rowA_wn(m, k);
+    const int nparts = rowA_grid_y(m, k);
+    void* ws;
+    rc = ssdseg_workspace(ctx, (size_t)nparts * 2 * k * sizeof(float), &ws);
+    if (rc) return rc;
+    a.bn_y = in->x; a.ldby = ldx; a.bn_s = in->scale; a.bn_t = in->shift; a.bn_mean = in_mean; a.bn_istd = in_invstd; a.bn_act = in->act;
+    a.bnpart = (float*)ws;
+    const dim3 grid(cdiv(k, 32 * wn), nparts, 1);
+    size_t lds = (size_t)(BM * AS + BK * (32 * wn + 1)) * sizeof(float);
+    const size_t cs = (size_t)64 * (32 * wn + 4) * sizeof(float);
+    if (cs > lds) lds = cs;
+    const double cost_bytes = 4.0 * ((dy->scale != nullptr ? 2.0 : 1.0) * m * n + 2.0 * m * k + (double)k * n);
+    const double cost_flops = 2.0 * m * k * n;
+    char kbuf[64];
+    snprintf(kbuf, sizeof(kbuf), "gemm_rowA_kernel<%d, 1, 0, 0, true>", wn);
+    const char* kname = ctx->timing ? ssdseg_intern(kbuf) : "";
+    switch (wn) {
+        case 1: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 0, true>), grid, dim3(256), lds, a); break;
+        case 2: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<2, 1, 0, 0, true>), grid, dim3(256), lds, a); break;
+        case 3: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<3, 1, 0, 0, true>), grid, dim3(256), lds, a); break;
+        case 4: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<4, 1, 0, 0, true>), grid, dim3(256), lds, a); break;
+        default: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<5, 1, 0, 0, true>), grid, dim3(256), lds, a); break;
+    }
+    SSDSEG_LAUNCH_CHECK();
+    return ssdseg_bn_bwd_finalize_launch(ctx, a.bnpart, nparts, k, (double)m, in->scale, in_mean, in_invstd, in_dgamma, in_dbeta, in_k1, in_k0);
 }
 
 int ssdseg_pwconv_bwd_weight(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssdseg_gview* dy, int ldy, float* dw,

@@ -243,6 +243,8 @@ class PwOp(Op):
             out.stats = eng.ctx.empty((out.nparts, 2, self.n))
         self.out_val: Optional[Val] = None
 
+    fuse_input_bn = False   # set by the lowering when this conv is the only consumer of a (wide) BatchNorm(+ReLU) output
+
     def fwd(self):
         self.e.ctx.call("ssdseg_pwconv_fwd", self.inp.view(), self.inp.store.ld, self.w, self.out.buf, self.out.ld, self.m, self.k, self.n,
                         self.out.stats)
@@ -250,6 +252,15 @@ class PwOp(Op):
     def bwd(self):
         s = self.inp.store
         gv = self.out_val.gview()
+        b = self.inp.bn
+        if (self.fuse_input_bn and b is not None and s.need_grad and s.pending is None and not s._written()):
+            # sole consumer of a BatchNorm(+ReLU6) output (the depthwise BN in front of a project conv): that BN's backward
+            # reduction rides in this conv's backward-data epilogue instead of a separate pass over (g, y)
+            dx, _ = s.grad_slot()
+            self.e.ctx.call("ssdseg_pwconv_bwd_bn", self.inp.view(), s.ld, gv, self.out.ld, self.w, dx, s.ld, self.dw, self.m, self.k, self.n,
+                            b.mean, b.invstd, b.dgamma, b.dbeta, b.k1, b.k0)
+            b.bwd_done = True
+            return
         if s.need_grad:
             # dx and dW in one call: for few input channels (the expand convs) one kernel reads the wide gradient once
             dx, acc, res, ldr = s.grad_slot_residual()
@@ -822,6 +833,11 @@ class Engine:
             assert layer.strides == (1, 1) and not layer.use_bias
             st = self._out_store(layer, out_t.shape)
             op = self._emit(PwOp(self, layer, "kernel", v, st))
+            src = layer.inbound[0]
+            # only for wide inputs (the 6x depthwise tensor in front of a project conv); the narrow block-input tensors in front of
+            # expand convs take the fused dx+dW kernel instead
+            op.fuse_input_bn = (v.bn is not None and v.store.c > layer.filters and v.store.parent is None
+                                and len(self.cons.get(id(src), [])) == 1 and id(src) not in {id(t) for t in self.model.outputs})
         elif layer.kernel_size == (3, 3):
             assert layer.strides == (1, 1) and not layer.use_bias and layer.dilation_rate == (1, 1)
             st = self._out_store(layer, out_t.shape)

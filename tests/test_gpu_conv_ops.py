@@ -22,6 +22,8 @@ def make_view_inputs(rng, shape, act):
     x = rng.normal(0, 2.0, shape).astype(np.float32)
     scale = rng.uniform(0.5, 1.5, c).astype(np.float32)
     shift = rng.uniform(-1, 3, c).astype(np.float32)
+    z = x.astype(np.float64) * scale + shift   # keep pre-activations off the ReLU6 thresholds (see make_gview_inputs)
+    x = np.where((np.abs(z) < 1e-3) | (np.abs(z - 6) < 1e-3), x + np.float32(0.05), x).astype(np.float32)
     a = O.act_fwd(x * scale + shift, act)
     return x, scale, shift, a
 
@@ -188,6 +190,24 @@ def test_pwconv_fwd_bwd(ctx, rng, kernel_family, m, k, n):
     ctx.call("ssdseg_pwconv_bwd", H.view(dx_), k, H.gview(bufs[0]), n, dw_, dxg, k, dwg, m, k, n, None, 0, 0)
     assert rel_err(dxg.download(), g.astype(np.float64) @ wgt.astype(np.float64).T) < 2e-5
     assert rel_err(dwg.download(), x.astype(np.float64).T @ g.astype(np.float64)) < 5e-5
+    # dx + dW + the BatchNorm backward of the layer feeding the conv (x is that BN's raw input), fused in the float4 epilogue
+    mean = x.mean(axis=0, dtype=np.float64).astype(np.float32)
+    invstd = (1.0 / np.sqrt(x.var(axis=0, dtype=np.float64) + 1e-3)).astype(np.float32)
+    outs = [ctx.empty(k) for _ in range(4)]
+    ctx.call("ssdseg_pwconv_bwd_bn", H.view(dx_, dsc, dsh, act), k, gv, n, dw_, dxg, k, dwg, m, k, n, ctx.array(mean), ctx.array(invstd), *outs)
+    assert rel_err(dxg.download(), dx_ref) < 2e-5
+    assert rel_err(dwg.download(), dw_ref) < 5e-5
+    z = x.astype(np.float64) * sc + sh
+    mg = dx_ref * O.act_mask(z, act)
+    xhat = (x.astype(np.float64) - mean) * invstd
+    dbeta, dgamma = mg.sum(axis=0), (mg * xhat).sum(axis=0)
+    tol = 1e-4 * max(np.abs(dgamma).max(), np.abs(dbeta).max(), 1e-6)
+    assert np.abs(outs[0].download() - dgamma).max() < tol
+    assert np.abs(outs[1].download() - dbeta).max() < tol
+    k1_ref = -sc.astype(np.float64) * dgamma * invstd / m
+    k0_ref = sc.astype(np.float64) * (dgamma * invstd * mean - dbeta) / m
+    assert np.abs(outs[2].download() - k1_ref).max() < 1e-4 * max(np.abs(k1_ref).max(), 1e-9)
+    assert np.abs(outs[3].download() - k0_ref).max() < 1e-4 * max(np.abs(k0_ref).max(), 1e-9)
 
 
 def test_pwconv_strided_concat_slice(ctx, rng):
