@@ -90,10 +90,12 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 // is re-read as rows of float4 (thread = fixed float4 column, several rows), added to residual / previous contents, stored
 // with 16-byte lanes, and in the same pass reduced into the BatchNorm-backward sums of the layer that produced this conv's
 // input (one extra read of that layer's raw output instead of a separate two-tensor reduction pass).
-template <int WN, int MODE, int LD, int NT = 0, bool BNE = false>
+// EP: 0 = scalar epilogue straight from the accumulators, 1 = the float4 epilogue, 2 = float4 epilogue + BN backward sums
+template <int WN, int MODE, int LD, int NT = 0, int EP = 0>
 __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
-    constexpr bool CONV = LD == 1, STEM = LD == 2, FUSEW = NT > 0;
-    static_assert(!BNE || (MODE == 1 && LD == 0 && NT == 0), "BN epilogue only for plain backward-data");
+    constexpr bool CONV = LD == 1, STEM = LD == 2, FUSEW = NT > 0, F4 = EP >= 1, BNE = EP == 2;
+    static_assert(!F4 || (LD == 0 && NT == 0), "float4 epilogue only for the plain pointwise GEMM");
+    static_assert(!BNE || MODE == 1, "BN epilogue only for backward-data");
     static_assert(!FUSEW || (MODE == 1 && LD == 0 && WN == 1), "fused dW only for plain backward-data with one column tile");
     constexpr int BN = 32 * WN;
     constexpr int BS = BN + 1;
@@ -316,7 +318,7 @@ __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
         for (int e = 0; e < 16; ++e) acc[0][e] += accb[e];
     }
 
-    if (BNE) {
+    if (F4) {
         constexpr int CS = BN + 4;        // LDS row stride of the transposed tile (float4-aligned)
         constexpr int CV = BN / 4;        // float4 columns
         constexpr int RPP = 256 / CV;     // rows per pass of the 256 threads
@@ -340,16 +342,17 @@ __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
                     const int m = m0 + h * 64 + row;
                     if (m >= p.I) break;
                     float4 v = ld4(Cs + row * CS + ec4 * 4);
-                    if (p.residual) {
+                    if (MODE == 1 && p.residual) {
                         const float4 r4 = ld4(p.residual + (long long)m * p.ldr + ej);
                         v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
                     }
                     float* o = p.out + (long long)m * p.ldo + ej;
-                    if (p.accumulate) {
+                    if (MODE == 1 && p.accumulate) {
                         const float4 o4 = ld4(o);
                         v.x += o4.x; v.y += o4.y; v.z += o4.z; v.w += o4.w;
                     }
                     st4(o, v);
+                    if (!BNE) continue;
                     const float4 yv = ld4(p.bn_y + (long long)m * p.ldby + ej);
                     float4 mg;
                     mg.x = (fmaf(ebs.x, yv.x, ebt.x) > bnlo && fmaf(ebs.x, yv.x, ebt.x) < bnhi) ? v.x : 0.f;
@@ -388,7 +391,7 @@ __global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
             }
         }
     }
-    }   // !BNE
+    }   // !F4
     if (MODE == 0 && p.stats != nullptr) {
         // per-channel (sum, sumsq) of this 128-row tile; padded rows are exactly zero
 #pragma unroll
@@ -837,6 +840,24 @@ int launch_rowA(ssdseg_ctx* ctx, const RowAArgs& a0) {
         SSDSEG_LAUNCH_CHECK();
         return 0;
     }
+    // wide, 16-byte-aligned outputs leave through the LDS-transposed float4 epilogue (16 B per lane instead of 4)
+    const char* f4env = getenv("SSDSEG_NO_F4_EPILOGUE");
+    if (LD == 0 && splits == 1 && wn >= 2 && !(f4env != nullptr && f4env[0] == '1') && a.J % 4 == 0 && a.ldo % 4 == 0 &&
+        ((uintptr_t)a.out & 15) == 0 && (a.residual == nullptr || (a.ldr % 4 == 0 && ((uintptr_t)a.residual & 15) == 0))) {
+        const size_t cs = (size_t)64 * (32 * wn + 4) * sizeof(float);
+        if (cs > lds) lds = cs;
+        snprintf(kbuf, sizeof(kbuf), "gemm_rowA_kernel<%d, %d, 0, 0, 1>", wn, MODE);
+        const char* fname = ctx->timing ? ssdseg_intern(kbuf) : "";
+        constexpr int FM = LD == 0 ? MODE : 0;   // (only instantiated for LD == 0)
+        switch (wn) {
+            case 2: SSDSEG_LAUNCH_NAMED(ctx, fname, cost_bytes, cost_flops, (gemm_rowA_kernel<2, FM, 0, 0, 1>), grid, dim3(256), lds, a); break;
+            case 3: SSDSEG_LAUNCH_NAMED(ctx, fname, cost_bytes, cost_flops, (gemm_rowA_kernel<3, FM, 0, 0, 1>), grid, dim3(256), lds, a); break;
+            case 4: SSDSEG_LAUNCH_NAMED(ctx, fname, cost_bytes, cost_flops, (gemm_rowA_kernel<4, FM, 0, 0, 1>), grid, dim3(256), lds, a); break;
+            default: SSDSEG_LAUNCH_NAMED(ctx, fname, cost_bytes, cost_flops, (gemm_rowA_kernel<5, FM, 0, 0, 1>), grid, dim3(256), lds, a); break;
+        }
+        SSDSEG_LAUNCH_CHECK();
+        return 0;
+    }
     snprintf(kbuf, sizeof(kbuf), "gemm_rowA_kernel<%d, %d, %d, 0>", wn, MODE, LD);   // = the symbol rocprofv3 shows
     const char* kname = ctx->timing ? ssdseg_intern(kbuf) : "";
     switch (wn) {
@@ -1125,14 +1146,14 @@ int ssdseg_pwconv_bwd_bn(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const 
     const double cost_bytes = 4.0 * ((dy->scale != nullptr ? 2.0 : 1.0) * m * n + 2.0 * m * k + (double)k * n);
     const double cost_flops = 2.0 * m * k * n;
     char kbuf[64];
-    snprintf(kbuf, sizeof(kbuf), "gemm_rowA_kernel<%d, 1, 0, 0, true>", wn);
+    snprintf(kbuf, sizeof(kbuf), "gemm_rowA_kernel<%d, 1, 0, 0, 2>", wn);
     const char* kname = ctx->timing ? ssdseg_intern(kbuf) : "";
     switch (wn) {
-        case 1: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 0, true>), grid, dim3(256), lds, a); break;
-        case 2: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<2, 1, 0, 0, true>), grid, dim3(256), lds, a); break;
-        case 3: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<3, 1, 0, 0, true>), grid, dim3(256), lds, a); break;
-        case 4: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<4, 1, 0, 0, true>), grid, dim3(256), lds, a); break;
-        default: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<5, 1, 0, 0, true>), grid, dim3(256), lds, a); break;
+        case 1: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 0, 2>), grid, dim3(256), lds, a); break;
+        case 2: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<2, 1, 0, 0, 2>), grid, dim3(256), lds, a); break;
+        case 3: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<3, 1, 0, 0, 2>), grid, dim3(256), lds, a); break;
+        case 4: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<4, 1, 0, 0, 2>), grid, dim3(256), lds, a); break;
+        default: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<5, 1, 0, 0, 2>), grid, dim3(256), lds, a); break;
     }
     SSDSEG_LAUNCH_CHECK();
     return ssdseg_bn_bwd_finalize_launch(ctx, a.bnpart, nparts, k, (double)m, in->scale, in_mean, in_invstd, in_dgamma, in_dbeta, in_k1, in_k0);
