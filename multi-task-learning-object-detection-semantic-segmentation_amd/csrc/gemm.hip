@@ -703,6 +703,7 @@ int pick_wn(int n, long long row_blocks) {
 int rowA_wn(int rows, int cols) { return pick_wn(cols, cdiv(rows, BM)); }
 
 #include "gemm_wres.h"
+#include "conv3_wgrad.h"
 
 // 1: the resident kernels where they measured faster (default); 0: SSDSEG_NO_WRES=1, general kernels everywhere (A/B
 // measurements); 2: SSDSEG_WRES_FORCE=1, resident kernels for every shape that fits (the parity tests run that way)
@@ -1320,6 +1321,40 @@ int ssdseg_conv3x3_bwd_weight(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, c
     SSDSEG_ARG(n > 0 && h > 0 && wdt > 0, 6);
     SSDSEG_ARG(cin > 0 && cin % 4 == 0, 9);
     SSDSEG_ARG(cout > 0 && cout % 4 == 0, 10);
+    const char* c3env = getenv("SSDSEG_CONV3_WGRAD");   // "taps": the nine shifted GEMMs (A/B measurements, parity tests)
+    if (!(c3env != nullptr && !strcmp(c3env, "taps"))) {
+        // all nine taps in one pass (conv3_wgrad.h)
+        Conv9Args a{};
+        a.x = in->x; a.xs = in->scale; a.xt = in->shift; a.xact = in->act; a.ldx = ldx;
+        a.g = dy->g; a.y = dy->y; a.gs = dy->scale; a.gt = dy->shift; a.gk1 = dy->k1; a.gk0 = dy->k0; a.gact = dy->act;
+        a.n = n; a.h = h; a.w = wdt; a.K = cin; a.N = cout;
+        a.wchunks = cdiv(wdt, C9_PX);
+        a.steps = (long long)n * h * a.wchunks;
+        const int wn = cout > 32 ? 4 : 1;
+        const int gx = cdiv(cout, 32 * wn), gy = cdiv(cin, C9_KT);
+        long long splits = (2LL * ctx->num_cus) / ((long long)gx * gy);
+        if (splits > a.steps / 8) splits = a.steps / 8;
+        if (splits < 1) splits = 1;
+        a.steps_per_split = (a.steps + splits - 1) / splits;
+        splits = (a.steps + a.steps_per_split - 1) / a.steps_per_split;
+        void* ws;
+        int rc = ssdseg_workspace(ctx, (size_t)splits * 9 * cin * cout * sizeof(float), &ws);
+        if (rc) return rc;
+        a.part = (float*)ws;
+        const dim3 grid(gx, gy, (unsigned)splits);
+        const size_t lds = (size_t)(C9_PX * (32 * wn + 4) + 3 * C9_XW * C9_XS) * sizeof(float);
+        const double m = (double)n * h * wdt;
+        const double cost_bytes = 4.0 * (m * cin + (dy->scale != nullptr ? 2.0 : 1.0) * m * cout + 9.0 * cin * cout);
+        const double cost_flops = 18.0 * m * cin * cout;
+        if (wn == 4) SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (conv3_wgrad9_kernel<4>), grid, dim3(C9_THREADS), lds, a);
+        else SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (conv3_wgrad9_kernel<1>), grid, dim3(C9_THREADS), lds, a);
+        SSDSEG_LAUNCH_CHECK();
+        if (splits == 1) {
+            SSDSEG_HIP(hipMemcpyAsync(dw, a.part, (size_t)9 * cin * cout * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+            return 0;
+        }
+        return ssdseg_colsum(ctx, a.part, (int)splits, 9LL * cin * cout, dw);
+    }
     for (int tap = 0; tap < 9; ++tap) {
         WGradArgs a{};
         a.x = in->x; a.xs = in->scale; a.xt = in->shift; a.xact = in->act; a.ldx = ldx;

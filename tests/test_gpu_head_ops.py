@@ -38,8 +38,9 @@ def gview_inputs(rng, shape, act):
     return (g, y, scale, shift, k1, k0), dy.astype(np.float32)
 
 
-@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 9, 11, 16, 32), (1, 12, 16, 304, 256), (2, 8, 8, 256, 4), (1, 5, 5, 24, 8), (1, 1, 1, 8, 8)])
-def test_conv3x3_fwd_bwd(ctx, rng, n, h, w, cin, cout):
+@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 9, 11, 16, 32), (1, 12, 16, 304, 256), (2, 8, 8, 256, 4), (1, 5, 5, 24, 8), (1, 1, 1, 8, 8),
+                                            (3, 14, 40, 72, 96)])   # 40 = one full + one partial 32-pixel step per image row
+def test_conv3x3_fwd_bwd(ctx, rng, monkeypatch, n, h, w, cin, cout):
     from ssdseglib import _hip as H
     act = O.ACT_RELU6
     x, sc, sh, a = view_inputs(rng, (n, h, w, cin), act)
@@ -64,6 +65,10 @@ def test_conv3x3_fwd_bwd(ctx, rng, n, h, w, cin, cout):
     ctx.call("ssdseg_conv3x3_bwd_data", H.gview(*bufs, act=O.ACT_RELU6), dw_, ddx, cin, n, h, w, cin, cout, 1)
     assert rel_err(ddx.download(), dx_ref + base) < 2e-5
     ddw = ctx.empty(wgt.shape)
+    ctx.call("ssdseg_conv3x3_bwd_weight", H.view(dx_, dsc, dsh, act), cin, H.gview(*bufs, act=O.ACT_RELU6), ddw, n, h, w, cin, cout)
+    assert rel_err(ddw.download(), dw_ref) < 5e-5      # default: all nine taps in one pass (conv3_wgrad.h)
+    monkeypatch.setenv("SSDSEG_CONV3_WGRAD", "taps")   # the nine shifted weight-gradient GEMMs
+    ddw.upload(np.zeros(wgt.shape, np.float32))
     ctx.call("ssdseg_conv3x3_bwd_weight", H.view(dx_, dsc, dsh, act), cin, H.gview(*bufs, act=O.ACT_RELU6), ddw, n, h, w, cin, cout)
     assert rel_err(ddw.download(), dw_ref) < 5e-5
 
