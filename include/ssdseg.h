@@ -187,6 +187,11 @@ int ssdseg_conv3x3_bwd_data(ssdseg_ctx* ctx, const ssdseg_gview* dy, const float
 int ssdseg_conv3x3_bwd_weight(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssdseg_gview* dy, float* dw,
                               int n, int h, int wdt, int cin, int cout);
 
+/* dy->g <- scale*mask(scale*y+shift)*g + k1*y + k0 in place: materialises a BatchNorm-backward gradient view ONCE for a consumer
+ * that would otherwise re-form it many times (the dense 3x3 conv reads every dy element 9x in backward-data and again in the
+ * weight gradient).  Afterwards the consumer uses the identity gradient view {dy->g}. */
+int ssdseg_gview_materialize(ssdseg_ctx* ctx, const ssdseg_gview* dy, int ld, int m, int c);
+
 /* ---------------------------------------------------------------- K7/K8: BatchNormalization (training) + activation
  * Keras BatchNormalization defaults eps 1e-3, momentum 0.99 (models.py:66,89,111,...; blocks.py:29,...).
  * finalize: partial (sum, sumsq)[nparts][2][c] over `count` samples per channel ->

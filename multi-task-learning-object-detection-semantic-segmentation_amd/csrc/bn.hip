@@ -239,6 +239,19 @@ __global__ void axpby_kernel(const float* __restrict__ src, int lds, float* __re
     }
 }
 
+// g <- dy = scale*mask(scale*y+shift)*g + k1*y + k0 in place (float4 per thread): materialises a BatchNorm-backward gradient view
+__global__ void gview_materialize_kernel(float* __restrict__ g, int ldg, const float* __restrict__ y, int ldy, const float* __restrict__ scale,
+                                         const float* __restrict__ shift, const float* __restrict__ k1, const float* __restrict__ k0, int act,
+                                         long long m, int cv) {
+    const long long total = m * cv;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / cv;
+        const int c0 = (int)(i % cv) * 4;
+        const float4 v = gview_apply4(ld4(g + r * ldg + c0), ld4(y + r * ldy + c0), ld4(scale + c0), ld4(shift + c0), ld4(k1 + c0), ld4(k0 + c0), act);
+        st4(g + r * ldg + c0, v);
+    }
+}
+
 struct RowLaunch {
     dim3 grid, block;
     size_t lds;
@@ -385,6 +398,19 @@ int ssdseg_bn_bwd_reduce(ssdseg_ctx* ctx, const float* g, int ldg, const float* 
                        (float*)ws);
     SSDSEG_LAUNCH_CHECK();
     return ssdseg_bn_bwd_finalize_launch(ctx, (const float*)ws, (int)l.grid.x, c, (double)m, scale, mean, invstd, dgamma, dbeta, k1, k0);
+}
+
+int ssdseg_gview_materialize(ssdseg_ctx* ctx, const ssdseg_gview* dy, int ld, int m, int c) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(dy != nullptr && dy->g != nullptr && dy->y != nullptr && dy->scale && dy->shift && dy->k1 && dy->k0, 2);
+    SSDSEG_ARG(ld >= c && ld % 4 == 0, 3);
+    SSDSEG_ARG(m > 0, 4);
+    SSDSEG_ARG(c > 0 && c % 4 == 0, 5);
+    const long long total = (long long)m * (c / 4);
+    SSDSEG_LAUNCH(ctx, 12.0 * m * c, 0.0, gview_materialize_kernel, dim3(ew_blocks(total)), dim3(256), 0, (float*)dy->g, ld, dy->y, ld, dy->scale,
+                  dy->shift, dy->k1, dy->k0, dy->act, (long long)m, c / 4);
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
 }
 
 int ssdseg_axpby(ssdseg_ctx* ctx, const float* src, int lds, float* dst, int ldd, int m, int c, float a, float b) {

@@ -289,6 +289,12 @@ class Conv3Op(Op):
     def bwd(self):
         s = self.inp.store
         gv = self.out_val.gview()
+        if self.out_val.bn is not None:
+            # both backward kernels read every dy element many times (9 taps): form dy = BN-backward(g, y) once, in place over g
+            # (nothing else reads this g afterwards), and hand them the single-tensor identity view
+            o = self.out
+            self.e.ctx.call("ssdseg_gview_materialize", gv, o.ld, o.m, o.c)
+            gv = H.gview(o.grad)
         self.e.ctx.side(True)      # dW is off the critical path: side stream, concurrent with the backward-data conv
         try:
             self.e.ctx.call("ssdseg_conv3x3_bwd_weight", self.inp.view(), s.ld, gv, self.dw, s.n, s.h, s.w, s.c, self.out.c)

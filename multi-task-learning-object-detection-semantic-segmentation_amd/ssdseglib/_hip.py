@@ -87,6 +87,7 @@ _SIGNATURES = {
     "ssdseg_bn_apply": [_vp, _VP, _i, _VP, _i, _vp, _i, _i, _i],
     "ssdseg_bn_bwd_reduce": [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
     "ssdseg_axpby": [_vp, _vp, _i, _vp, _i, _i, _i, _f, _f],
+    "ssdseg_gview_materialize": [_vp, _GP, _i, _i, _i],
     "ssdseg_gap_fwd": [_vp, _VP, _vp, _i, _i, _i],
     "ssdseg_gap_bwd": [_vp, _vp, _vp, _i, _i, _i, _i],
     "ssdseg_bilinear_fwd": [_vp, _VP, _i, _vp, _i, _i, _i, _i, _i, _i, _i],
