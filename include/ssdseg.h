@@ -90,6 +90,9 @@ int ssdseg_ctx_join(ssdseg_ctx* ctx);
 /* on != 0: the launches that follow go to the side stream (after everything queued so far); on == 0: back to the ctx stream.
  * For callers that issue a weight-gradient entry point themselves (ssdseg_pwconv_bwd does this internally). */
 int ssdseg_ctx_side(ssdseg_ctx* ctx, int on);
+/* enabled == 0: everything on the ctx stream from now on (used by bench.py to time a kernel without a co-running neighbour);
+ * enabled != 0: side stream back on (if the ctx has one). */
+int ssdseg_ctx_side_enable(ssdseg_ctx* ctx, int enabled);
 int ssdseg_ctx_reserve(ssdseg_ctx* ctx, size_t workspace_bytes);
 int ssdseg_ctx_device_name(ssdseg_ctx* ctx, char* buf_host, size_t buf_len);
 int ssdseg_malloc(ssdseg_ctx* ctx, size_t bytes, void** out_host);

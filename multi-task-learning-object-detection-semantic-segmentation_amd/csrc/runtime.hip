@@ -291,6 +291,14 @@ int ssdseg_ctx_join(ssdseg_ctx* ctx) {
     return ssdseg_join(ctx);
 }
 
+int ssdseg_ctx_side_enable(ssdseg_ctx* ctx, int enabled) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    int rc = ssdseg_join(ctx);
+    if (rc) return rc;
+    ctx->side_ok = enabled != 0 && ctx->side_stream != nullptr && ctx->ev_fork != nullptr && ctx->ev_join != nullptr;
+    return 0;
+}
+
 int ssdseg_ctx_side(ssdseg_ctx* ctx, int on) {
     SSDSEG_ARG(ctx != nullptr, 1);
     if (on) (void)ssdseg_side_begin(ctx);

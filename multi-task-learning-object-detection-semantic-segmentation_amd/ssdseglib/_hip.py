@@ -44,6 +44,7 @@ _SIGNATURES = {
     "ssdseg_ctx_sync": [_vp],
     "ssdseg_ctx_join": [_vp],
     "ssdseg_ctx_side": [_vp, _i],
+    "ssdseg_ctx_side_enable": [_vp, _i],
     "ssdseg_ctx_reserve": [_vp, _sz],
     "ssdseg_ctx_device_name": [_vp, C.c_char_p, _sz],
     "ssdseg_malloc": [_vp, _sz, C.POINTER(_vp)],
@@ -298,6 +299,9 @@ class Context:
     def side(self, on: bool):
         """route the following launches to the side stream (weight gradients) / back to the ctx stream"""
         _check(self.lib.ssdseg_ctx_side(self.handle, 1 if on else 0), "ssdseg_ctx_side")
+
+    def side_enable(self, enabled: bool):
+        _check(self.lib.ssdseg_ctx_side_enable(self.handle, 1 if enabled else 0), "ssdseg_ctx_side_enable")
 
     def reserve(self, nbytes: int):
         _check(self.lib.ssdseg_ctx_reserve(self.handle, int(nbytes)), "ssdseg_ctx_reserve")
