@@ -40,9 +40,10 @@ struct MarchStage {   // raw loads of one step: dy row i+1 (g, y) and x row i
 };
 
 // WFULL: w % MTW == 0, the four owned columns always exist (only the two halo columns are conditional)
-template <bool BNFUSE, bool WFULL>
-__global__ void __launch_bounds__(256) dw_bwd_march_kernel(MarchGeom gm, ViewDev in, const float* __restrict__ wgt, GViewDev dy,
-                                                            float* __restrict__ dx, float* __restrict__ dwpart, int accumulate,
+// ACC: dx += result (fan-out taps) -- a template flag, not a run-time branch around every store
+template <bool BNFUSE, bool WFULL, bool ACC>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) dw_bwd_march_kernel(MarchGeom gm, ViewDev in, const float* __restrict__ wgt, GViewDev dy,
+                                                            float* __restrict__ dx, float* __restrict__ dwpart, int /*accumulate*/,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             float* __restrict__ bnpart) {
     extern __shared__ float mred[];   // [11][blockDim.x]
@@ -66,7 +67,7 @@ __global__ void __launch_bounds__(256) dw_bwd_march_kernel(MarchGeom gm, ViewDev
     const float is = iaff ? in.scale[chs] : 1.f, it = iaff ? in.shift[chs] : 0.f;
     const float gs = gaff ? dy.scale[chs] : 1.f, gt = gaff ? dy.shift[chs] : 0.f;
     const float gk1 = gaff ? dy.k1[chs] : 0.f, gk0 = gaff ? dy.k0[chs] : 0.f;
-    float mu = 0.f, istd = 0.f;
+    float mu = 0.f, istd = 0.f;   // xhat = (x - mu) * istd: the subtraction first (exact for x == mu), not x*istd - mu*istd
     if (BNFUSE) { mu = mean[chs]; istd = invstd[chs]; }
     float wk[9];
 #pragma unroll
@@ -104,31 +105,33 @@ __global__ void __launch_bounds__(256) dw_bwd_march_kernel(MarchGeom gm, ViewDev
             }
         };
         auto make_dy = [&](int row, const float (&g)[MWC], const float (&y)[MWC], float (&d)[MWC]) {
+            // a row outside the image contributes nothing: fold that into the three per-row coefficients instead of six selects
             const bool rok = row >= 0 && row < gm.h;
+            const float gsr = rok ? gs : 0.f, k1r = rok ? gk1 : 0.f, k0r = rok ? gk0 : 0.f;
 #pragma unroll
             for (int a = 0; a < MWC; ++a) {
                 const float z = fmaf(gs, y[a], gt);
-                const float m = (z > glo && z < ghi) ? gs : 0.f;
-                const float v = fmaf(m, g[a], fmaf(gk1, y[a], gk0));
-                d[a] = (rok && cok[a]) ? v : 0.f;
+                const float m = (z > glo && z < ghi) ? gsr : 0.f;
+                const float v = fmaf(m, g[a], fmaf(k1r, y[a], k0r));
+                d[a] = (WFULL && a >= 1 && a <= MTW) ? v : (cok[a] ? v : 0.f);
             }
         };
-        float dm[MWC], d0[MWC], dp[MWC];
+        float wa[MWC], wb[MWC], wc[MWC];   // the rolling dy window; which array is row i-1 / i / i+1 rotates with the step
         {
             MarchStage p;
             issue(r0 - 1, r0, p);
-            make_dy(r0 - 1, p.g, p.y, dm);
+            make_dy(r0 - 1, p.g, p.y, wa);
             issue(r0, r0, p);
-            make_dy(r0, p.g, p.y, d0);
+            make_dy(r0, p.g, p.y, wb);
         }
-        // one row: consume `cur` (dy row i+1, x row i), refill `nxt` for row i+1
-        auto step = [&](int i, MarchStage& cur, MarchStage& nxt) {
+        // one row: consume `cur` (dy row i+1, x row i), refill `nxt` for row i+1.  dm / d0 hold dy rows i-1 / i, dp receives i+1.
+        auto step = [&](int i, MarchStage& cur, MarchStage& nxt, const float (&dm)[MWC], const float (&d0)[MWC], float (&dp)[MWC]) {
             float xa[MWC];
             make_dy(i + 1, cur.g, cur.y, dp);
 #pragma unroll
             for (int a = 0; a < MWC; ++a) {
                 const float z = fminf(fmaxf(fmaf(is, cur.x[a], it), ilo), ihi);
-                xa[a] = cok[a] ? z : 0.f;
+                xa[a] = (WFULL && a >= 1 && a <= MTW) ? z : (cok[a] ? z : 0.f);
             }
             // next step's loads go out before this step's arithmetic.  Unconditional (the last step re-reads row r1-1 into
             // registers nobody consumes): a branch here makes the compiler's s_waitcnt placement merge the "no new loads"
@@ -148,7 +151,7 @@ __global__ void __launch_bounds__(256) dw_bwd_march_kernel(MarchGeom gm, ViewDev
                 if (WFULL || cok[j + 1]) {
                     if (dx != nullptr) {
                         float* p = reinterpret_cast<float*>(reinterpret_cast<char*>(dx) + (ob + coff[j + 1]));
-                        if (accumulate) acc += *p;
+                        if (ACC) acc += *p;
                         *p = acc;
                     }
                     if (BNFUSE) {
@@ -168,17 +171,19 @@ __global__ void __launch_bounds__(256) dw_bwd_march_kernel(MarchGeom gm, ViewDev
                     dwacc[2 * 3 + kw] = fmaf(xa[j + kw], dm[j + 1], dwacc[2 * 3 + kw]);
                 }
             }
-#pragma unroll
-            for (int a = 0; a < MWC; ++a) { dm[a] = d0[a]; d0[a] = dp[a]; }
         };
         MarchStage sa, sb2;
         issue(r0 + 1, r0, sa);
         int i = r0;
-        for (; i + 1 < r1; i += 2) {   // straight-line pairs: both staging sets keep their roles across the back edge
-            step(i, sa, sb2);
-            step(i + 1, sb2, sa);
+        // two rows per trip (the two staging sets are back in their roles at the back edge); the three-array window is rotated
+        // by copying -- unrolling six rows to make that free as well costs 90 more VGPRs (214), i.e. half the occupancy
+        for (; i + 1 < r1; i += 2) {
+            step(i, sa, sb2, wa, wb, wc);
+            step(i + 1, sb2, sa, wb, wc, wa);
+#pragma unroll
+            for (int a = 0; a < MWC; ++a) { const float t0 = wa[a]; wa[a] = wc[a]; wc[a] = wb[a]; wb[a] = t0; }
         }
-        if (i < r1) step(i, sa, sb2);
+        if (i < r1) step(i, sa, sb2, wa, wb, wc);
     }
 
     // ---- block partials: sum over the block's strips (fixed order), one row per spatial block
