@@ -859,7 +859,7 @@ int launch_rowA(ssdseg_ctx* ctx, const RowAArgs& a0) {
         SSDSEG_LAUNCH_CHECK();
         return 0;
     }
-    snprintf(kbuf, sizeof(kbuf), "gemm_rowA_kernel<%d, %d, %d, 0>", wn, MODE, LD);   // = the symbol rocprofv3 shows
+    snprintf(kbuf, sizeof(kbuf), "gemm_rowA_kernel<%d, %d, %d, 0, 0>", wn, MODE, LD);   // = the symbol rocprofv3 shows
     const char* kname = ctx->timing ? ssdseg_intern(kbuf) : "";
     switch (wn) {
         case 1: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, MODE, LD>), grid, dim3(256), lds, a); break;
@@ -1075,7 +1075,7 @@ int ssdseg_pwconv_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssd
         return ssdseg_colsum(ctx, a.wpart, gy, (long long)k * n, dw);
     }
     char fbuf[64];
-    snprintf(fbuf, sizeof(fbuf), "gemm_rowA_kernel<1, 1, 0, %d>", nt > 6 ? 6 : nt);   // NT > 0: fused dW
+    snprintf(fbuf, sizeof(fbuf), "gemm_rowA_kernel<1, 1, 0, %d, 0>", nt > 6 ? 6 : nt);   // NT > 0: fused dW
     const char* kname = ctx->timing ? ssdseg_intern(fbuf) : "";
     switch (nt) {
         case 1: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 1>), grid, dim3(256), lds, a); break;

@@ -16,11 +16,11 @@ stem = f"{rnd}_{workload}_b{batch}"
 
 
 def cp(pattern, name):
-    files = glob.glob(os.path.join(src, pattern), recursive=True)
+    files = sorted(glob.glob(os.path.join(src, pattern), recursive=True), key=os.path.getmtime)
     if not files:
         print("missing", pattern)
         return
-    shutil.copyfile(files[0], os.path.join(dst, name))
+    shutil.copyfile(files[-1], os.path.join(dst, name))     # newest (gpurun_out/ accumulates across calls)
     print("->", name)
 
 
