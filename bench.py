@@ -47,12 +47,20 @@ def default_boxes():
     return b
 
 
-def build_models(seed=1993):
-    """-> (boxes, builder, full training model, backbone-only model) for the NB03 configuration"""
+def build_models(seed=1993, kind="mobilenetv2"):
+    """-> (boxes, builder) for the NB03 configuration; kind "shufflenetv2" = SURVEY.md 8(d) config 5 ('1x', additional depthwise
+    convolution, residual connections; the reference's quirk Q1 -- heads built with ReLU(max_value=0.0) -- kept bug-compatible)"""
     import ssdseglib
     from ssdseglib import _graph as K
     K.set_seed(seed)
     boxes = default_boxes()
+    if kind == "shufflenetv2":
+        return boxes, ssdseglib.models.ShuffleNetV2SsdSegBuilder(
+            input_image_shape=IMAGE_SHAPE, model_size='1x', use_additional_depthwise_convolution=True, use_residual_connections=True,
+            number_of_boxes_per_point=[6, 6, 6, 6], number_of_classes=4,
+            center_x_boxes_default=boxes.get_boxes_coordinates_center_x('ssd'), center_y_boxes_default=boxes.get_boxes_coordinates_center_y('ssd'),
+            width_boxes_default=boxes.get_boxes_coordinates_width('ssd'), height_boxes_default=boxes.get_boxes_coordinates_height('ssd'),
+            standard_deviations_centroids_offsets=STDS)
     builder = ssdseglib.models.MobileNetV2SsdSegBuilder(
         input_image_shape=IMAGE_SHAPE, number_of_boxes_per_point=[6, 6, 6, 6], number_of_classes=4,
         center_x_boxes_default=boxes.get_boxes_coordinates_center_x('ssd'), center_y_boxes_default=boxes.get_boxes_coordinates_center_y('ssd'),
@@ -68,9 +76,9 @@ def build_backbone_model():
     return K.Model(inputs=inp, outputs=[b._layers[n] for n in TAPS])
 
 
-def build_full_model():
+def build_full_model(kind="mobilenetv2"):
     import ssdseglib
-    boxes, b = build_models()
+    boxes, b = build_models(kind=kind)
     model = b.get_model_for_training('deeplabv3plus', 'ssdlite', segmentation_dilation_rates=(3, 6, 12))     # NB03#cell12
     model.compile(optimizer=ssdseglib.optimizers.Adam(learning_rate=1e-4),
                   loss={'output-mask': ssdseglib.losses.cross_entropy(classes_weights=CLASS_WEIGHTS),
@@ -135,9 +143,11 @@ class FullStep:
     workload = ("BASELINE.json configs[2]: full MobileNetV2-SSDLite-DeepLabV3+ train step (anchor encode + fwd + weighted CE / "
                 "confidence+mining / localization losses + bwd (+all-reduce) + Adam), batch 32/GPU, 480x640x3, 9600 anchors, 4 classes")
 
+    kind = "mobilenetv2"
+
     def __init__(self, ctx, batch, rank, reducer, grad_bucket=None):
         from ssdseglib import _engine as E
-        boxes, self.model = build_full_model()
+        boxes, self.model = build_full_model(self.kind)
         self.eng = E.Engine(self.model, batch, training=True, ctx=ctx, grad_bucket=grad_bucket)
         self.eng.configure_losses(self.model._compiled["loss"], self.model._compiled["loss_weights"])
         self.reducer, self.ctx, self.batch = reducer, ctx, batch
@@ -160,6 +170,17 @@ class FullStep:
         e.adam_step(lr=1e-4, grad_scale=self.reducer.scale if self.reducer is not None else 1.0)
 
 
+class ShuffleNetStep(FullStep):
+    """configs[4] per GPU: the same train step on the ShuffleNetV2 1x variant (channel shuffle / split / max-pool kernels)"""
+    workload = ("BASELINE.json configs[4] (per-GPU share): full ShuffleNetV2-1x-SSDLite-DeepLabV3+ train step (additional depthwise "
+                "convolution + residual connections; anchor encode + fwd + 3 losses + bwd (+all-reduce) + Adam), batch 32/GPU, 480x640x3, "
+                "9600 anchors, 4 classes; reference quirk Q1 (heads' ReLU max_value 0.0) kept bug-compatible")
+    kind = "shufflenetv2"
+
+
+STEPS = {"backbone": BackboneStep, "full": FullStep, "shufflenet": ShuffleNetStep}
+
+
 def cpu_baseline(workload, sample_batch=1):
     """NumPy oracle of the same step on the host cores, bounded sample (kind "port": TensorFlow cannot run here)."""
     from oracle import np_ops as O
@@ -173,7 +194,7 @@ def cpu_baseline(workload, sample_batch=1):
         outs = ref.forward(x, training=True)
         gouts = [(rng.standard_normal(o.shape, dtype=np.float32) * np.float32(1e-3)) for o in outs]
     else:
-        boxes, model = build_full_model()
+        boxes, model = build_full_model("shufflenetv2" if workload == "shufflenet" else "mobilenetv2")
         gt, cnt, mask = synthetic_ground_truth(sample_batch, 11)
         ref = NpModel(model, dtype=np.float32)
         corners = boxes.get_boxes_coordinates_corners('ssd')
@@ -265,7 +286,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
-    ap.add_argument("--workload", default="backbone", choices=["backbone", "full"])
+    ap.add_argument("--workload", default="backbone", choices=["backbone", "full", "shufflenet"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events in the timed region")
     args = ap.parse_args()
@@ -283,10 +304,19 @@ def main():
     grad_bucket = None
     if world > 1:
         import torch
-        dist = P.init_process_group(backend="nccl", device_index=local_rank)
-        # our kernels and the RCCL collective are ordered on torch's current stream (borrowed, not owned, by the ctx)
-        ctx = H.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
-        model_for_count = build_backbone_model() if args.workload == "backbone" else build_full_model()[1]
+        # rehearsal switches (one-GPU box): SSDSEG_BENCH_BACKEND=gloo SSDSEG_BENCH_DEVICE=0 runs all ranks on one card over gloo
+        backend = os.environ.get("SSDSEG_BENCH_BACKEND", "nccl")
+        device = int(os.environ.get("SSDSEG_BENCH_DEVICE", local_rank))
+        torch.cuda.set_device(device)
+        dist = P.init_process_group(backend=backend, device_index=device)
+        # our kernels and the RCCL collective are ordered on ONE torch stream (borrowed, not owned, by the ctx): a non-blocking
+        # high-priority stream made current, so the collective's stream-ordering hooks and our launches agree on it
+        main_stream = torch.cuda.Stream(device=device, priority=-1)
+        torch.cuda.set_stream(main_stream)
+        local_rank = device
+        ctx = H.Context(device, stream=main_stream.cuda_stream)
+        model_for_count = (build_backbone_model() if args.workload == "backbone" else
+                           build_full_model("shufflenetv2" if args.workload == "shufflenet" else "mobilenetv2")[1])
         n_params = sum(int(l.weights[w].size) for l in model_for_count.layers for w in l.trainable_names)
         bucket_t = torch.zeros(n_params, dtype=torch.float32, device=f"cuda:{local_rank}")
         grad_bucket = ctx.borrow(bucket_t.data_ptr(), (n_params,), np.float32, owner=bucket_t)
@@ -294,7 +324,7 @@ def main():
     else:
         ctx = H.Context(local_rank)
 
-    step = (BackboneStep if args.workload == "backbone" else FullStep)(ctx, args.batch, rank, reducer, grad_bucket)
+    step = STEPS[args.workload](ctx, args.batch, rank, reducer, grad_bucket)
 
     def barrier():
         ctx.sync()

@@ -18,6 +18,7 @@
 namespace {
 
 constexpr int MTW = 4;        // output columns per thread
+constexpr int MARCH_MAX_THREADS = 512;
 constexpr int MWC = MTW + 2;  // window columns
 
 struct MarchGeom {
@@ -42,7 +43,7 @@ struct MarchStage {   // raw loads of one step: dy row i+1 (g, y) and x row i
 // WFULL: w % MTW == 0, the four owned columns always exist (only the two halo columns are conditional)
 // ACC: dx += result (fan-out taps) -- a template flag, not a run-time branch around every store
 template <bool BNFUSE, bool WFULL, bool ACC>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) dw_bwd_march_kernel(MarchGeom gm, ViewDev in, const float* __restrict__ wgt, GViewDev dy,
+__global__ void __launch_bounds__(MARCH_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) dw_bwd_march_kernel(MarchGeom gm, ViewDev in, const float* __restrict__ wgt, GViewDev dy,
                                                             float* __restrict__ dx, float* __restrict__ dwpart, int /*accumulate*/,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             float* __restrict__ bnpart) {
@@ -208,16 +209,38 @@ struct MarchLaunch {
     size_t lds;
 };
 
+// Block shape of the marching kernels: `cb` channels x `spb` ADJACENT column strips.  Strips of one block march in step, so
+// the horizontal halo between them is served by L1; between blocks it is not (neighbouring blocks drift apart by more rows
+// than L2 holds: PMC FETCH_SIZE showed the full 6/4 halo for one-strip blocks, 1.05x for the eight-strip blocks of c = 32).
+// So: channel chunks of 64 (one wave = one strip's 256-byte pixel segment, line-aligned because c % 64 == 0), as many
+// strips as fit in MARCH_MAX_THREADS, the count chosen to waste the fewest strip slots in the last group of a row.
+inline void march_split(int c, int wstrips, int* cb_out, int* spb_out, int* cchunks_out) {
+    static const int env_cb = getenv("SSDSEG_MARCH_CB") ? atoi(getenv("SSDSEG_MARCH_CB")) : 0;        // A/B switches
+    static const int env_mt = getenv("SSDSEG_MARCH_MAXT") ? atoi(getenv("SSDSEG_MARCH_MAXT")) : 0;
+    const int maxt = (env_mt >= 64 && env_mt <= MARCH_MAX_THREADS) ? env_mt : 256;   // 512-thread blocks measured 3-5 % slower
+    int unit = env_cb > 0 ? env_cb : 64;
+    int cb, cchunks;
+    if (env_cb >= 0 && c > unit && c % unit == 0) { cb = unit; cchunks = c / unit; }
+    else { cchunks = cdiv(c, 256); cb = cdiv(c, cchunks); }
+    int maxspb = maxt / cb;
+    if (maxspb < 1) maxspb = 1;
+    if (maxspb > wstrips) maxspb = wstrips;
+    int best = 1, bestwaste = 1 << 30;
+    for (int sp = maxspb; sp >= 1; --sp) {
+        const int waste = cdiv(wstrips, sp) * sp - wstrips;
+        // fewer strips per block only if it saves strip slots AND keeps at least half of the halo sharing
+        if (waste < bestwaste && (sp * 2 > maxspb || bestwaste == (1 << 30))) { best = sp; bestwaste = waste; }
+    }
+    *cb_out = cb; *spb_out = best; *cchunks_out = cchunks;
+}
+
 // geometry for an n x h x w x c tensor: channel chunks of <= 256, as many strips per block as fit in 256 threads, row chunks
 // sized so that the launch has >= ~4096 waves (16 per CU) where the layer is big enough
 inline MarchLaunch march_geometry(int n, int h, int w, int c, MarchGeom* g) {
     g->n = n; g->h = h; g->w = w; g->c = c;
     g->wstrips = cdiv(w, MTW);
-    const int cchunks = cdiv(c, 256);
-    g->cb = cdiv(c, cchunks);
-    g->spb = 256 / g->cb;
-    if (g->spb < 1) g->spb = 1;
-    if (g->spb > g->wstrips) g->spb = g->wstrips;
+    int cchunks;
+    march_split(c, g->wstrips, &g->cb, &g->spb, &cchunks);
     g->sgroups = cdiv(g->wstrips, g->spb);
     const int threads = ((g->cb * g->spb + 63) / 64) * 64;
     const long long waves_per_chunkrow = (long long)n * g->sgroups * cchunks * (threads / 64);
@@ -250,7 +273,7 @@ struct March2Geom {
 };
 
 template <bool BNFUSE, int PT, int PL>
-__global__ void __launch_bounds__(256) dw_bwd_march2_kernel(March2Geom gm, ViewDev in, const float* __restrict__ wgt, GViewDev dy,
+__global__ void __launch_bounds__(MARCH_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) dw_bwd_march2_kernel(March2Geom gm, ViewDev in, const float* __restrict__ wgt, GViewDev dy,
                                                              float* __restrict__ dx, float* __restrict__ dwpart, int accumulate,
                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
                                                              float* __restrict__ bnpart) {
@@ -435,7 +458,7 @@ __global__ void __launch_bounds__(256) dw_bwd_march2_kernel(March2Geom gm, ViewD
 // BN statistics (sum, sumsq of the raw output) stay in registers and leave as one partial row per block.
 // `gm` is a March2Geom in both cases (h, w input; ho, wo output; strips over output columns).
 template <int S, int PT, int PL>
-__global__ void __launch_bounds__(256) dw_fwd_march_kernel(March2Geom gm, ViewDev in, const float* __restrict__ wgt, float* __restrict__ y,
+__global__ void __launch_bounds__(MARCH_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) dw_fwd_march_kernel(March2Geom gm, ViewDev in, const float* __restrict__ wgt, float* __restrict__ y,
                                                             float* __restrict__ stats) {
     constexpr int OC = S == 1 ? 4 : 2;        // output columns per thread
     constexpr int IC = (OC - 1) * S + 3;      // input columns per thread (6 | 5)
@@ -568,11 +591,8 @@ __global__ void __launch_bounds__(256) dw_fwd_march_kernel(March2Geom gm, ViewDe
 inline MarchLaunch march_fwd_geometry(int n, int h, int w, int c, int ho, int wo, int stride, March2Geom* g) {
     g->n = n; g->h = h; g->w = w; g->c = c; g->ho = ho; g->wo = wo;
     g->wstrips = cdiv(wo, stride == 1 ? 4 : 2);
-    const int cchunks = cdiv(c, 256);
-    g->cb = cdiv(c, cchunks);
-    g->spb = 256 / g->cb;
-    if (g->spb < 1) g->spb = 1;
-    if (g->spb > g->wstrips) g->spb = g->wstrips;
+    int cchunks;
+    march_split(c, g->wstrips, &g->cb, &g->spb, &cchunks);
     g->sgroups = cdiv(g->wstrips, g->spb);
     const int threads = ((g->cb * g->spb + 63) / 64) * 64;
     const long long waves_per_chunkrow = (long long)n * g->sgroups * cchunks * (threads / 64);
@@ -591,11 +611,8 @@ inline MarchLaunch march_fwd_geometry(int n, int h, int w, int c, int ho, int wo
 inline MarchLaunch march2_geometry(int n, int h, int w, int c, int ho, int wo, March2Geom* g) {
     g->n = n; g->h = h; g->w = w; g->c = c; g->ho = ho; g->wo = wo;
     g->wstrips = cdiv(wo, 2);
-    const int cchunks = cdiv(c, 256);
-    g->cb = cdiv(c, cchunks);
-    g->spb = 256 / g->cb;
-    if (g->spb < 1) g->spb = 1;
-    if (g->spb > g->wstrips) g->spb = g->wstrips;
+    int cchunks;
+    march_split(c, g->wstrips, &g->cb, &g->spb, &cchunks);
     g->sgroups = cdiv(g->wstrips, g->spb);
     const int threads = ((g->cb * g->spb + 63) / 64) * 64;
     const long long waves_per_chunkrow = (long long)n * g->sgroups * cchunks * (threads / 64);
