@@ -91,8 +91,16 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 // with 16-byte lanes, and in the same pass reduced into the BatchNorm-backward sums of the layer that produced this conv's
 // input (one extra read of that layer's raw output instead of a separate two-tensor reduction pass).
 // EP: 0 = scalar epilogue straight from the accumulators, 1 = the float4 epilogue, 2 = float4 epilogue + BN backward sums
-template <int WN, int MODE, int LD, int NT = 0, int EP = 0>
-__global__ void __launch_bounds__(256) gemm_rowA_kernel(RowAArgs p) {
+// occupancy targets (waves per SIMD; a block is 4 waves = one per SIMD): the widest tile used to land at 264-300 registers,
+// i.e. ONE block per CU, where every barrier and every global->LDS hand-over idles the matrix pipe
+// (measured: conv backward-data 77 -> 96 TFLOP/s at two blocks per CU, the HBM-bound early pointwise layers +20-50 %).
+// OCC = 1 instantiations carry the target; OCC = 0 keeps the compiler's own allocation (accumulators in AGPRs, looser
+// schedule), which is what the short-M late layers want: they are latency- not occupancy-bound (too few blocks to fill the
+// chip twice anyway) and ran 10-25 % SLOWER with the tight allocation.  Dispatch: rows >= ROWA_OCC_ROWS.
+constexpr int rowa_min_waves(int WN, int MODE, int NT) { return NT > 0 ? 2 : (WN >= 2 ? 2 : (MODE == 0 ? 4 : 3)); }
+constexpr int ROWA_OCC_ROWS = 150000;
+template <int WN, int MODE, int LD, int NT = 0, int EP = 0, int OCC = 0>
+__global__ void __launch_bounds__(256, OCC ? rowa_min_waves(WN, MODE, NT) : 1) gemm_rowA_kernel(RowAArgs p) {
     constexpr bool CONV = LD == 1, STEM = LD == 2, FUSEW = NT > 0, F4 = EP >= 1, BNE = EP == 2;
     static_assert(!F4 || (LD == 0 && NT == 0), "float4 epilogue only for the plain pointwise GEMM");
     static_assert(!BNE || MODE == 1, "BN epilogue only for backward-data");
@@ -821,6 +829,7 @@ int launch_rowA(ssdseg_ctx* ctx, const RowAArgs& a0) {
     const double streamed = (MODE == 1 && a.cs != nullptr) ? 2.0 : 1.0;
     const double cost_bytes = 4.0 * (streamed * a.I * a.R + (double)a.I * a.J + (double)a.R * a.J);
     const double cost_flops = 2.0 * a.I * a.R * a.J;
+    const bool occ = a.I >= ROWA_OCC_ROWS;
     char kbuf[64];
     // Measured per layer on MI355X (profiles/r01_wres_vs_general_per_layer.txt): the resident kernel wins when every wave
     // streams several row tiles (>= ~500k rows: the 240x320 and 120x160 stages at batch 32) and loses 10-30 % below that,
@@ -847,26 +856,53 @@ int launch_rowA(ssdseg_ctx* ctx, const RowAArgs& a0) {
         ((uintptr_t)a.out & 15) == 0 && (a.residual == nullptr || (a.ldr % 4 == 0 && ((uintptr_t)a.residual & 15) == 0))) {
         const size_t cs = (size_t)64 * (32 * wn + 4) * sizeof(float);
         if (cs > lds) lds = cs;
-        snprintf(kbuf, sizeof(kbuf), "gemm_rowA_kernel<%d, %d, 0, 0, 1>", wn, MODE);
+        snprintf(kbuf, sizeof(kbuf), "gemm_rowA_kernel<%d, %d, 0, 0, 1, %d>", wn, MODE, (int)occ);
         const char* fname = ctx->timing ? ssdseg_intern(kbuf) : "";
         constexpr int FM = LD == 0 ? MODE : 0;   // (only instantiated for LD == 0)
         switch (wn) {
-            case 2: SSDSEG_LAUNCH_NAMED(ctx, fname, cost_bytes, cost_flops, (gemm_rowA_kernel<2, FM, 0, 0, 1>), grid, dim3(256), lds, a); break;
-            case 3: SSDSEG_LAUNCH_NAMED(ctx, fname, cost_bytes, cost_flops, (gemm_rowA_kernel<3, FM, 0, 0, 1>), grid, dim3(256), lds, a); break;
-            case 4: SSDSEG_LAUNCH_NAMED(ctx, fname, cost_bytes, cost_flops, (gemm_rowA_kernel<4, FM, 0, 0, 1>), grid, dim3(256), lds, a); break;
-            default: SSDSEG_LAUNCH_NAMED(ctx, fname, cost_bytes, cost_flops, (gemm_rowA_kernel<5, FM, 0, 0, 1>), grid, dim3(256), lds, a); break;
+            case 2:
+            if (occ) SSDSEG_LAUNCH_NAMED(ctx, fname, cost_bytes, cost_flops, (gemm_rowA_kernel<2, FM, 0, 0, 1, 1>), grid, dim3(256), lds, a);
+            else SSDSEG_LAUNCH_NAMED(ctx, fname, cost_bytes, cost_flops, (gemm_rowA_kernel<2, FM, 0, 0, 1, 0>), grid, dim3(256), lds, a);
+            break;
+            case 3:
+            if (occ) SSDSEG_LAUNCH_NAMED(ctx, fname, cost_bytes, cost_flops, (gemm_rowA_kernel<3, FM, 0, 0, 1, 1>), grid, dim3(256), lds, a);
+            else SSDSEG_LAUNCH_NAMED(ctx, fname, cost_bytes, cost_flops, (gemm_rowA_kernel<3, FM, 0, 0, 1, 0>), grid, dim3(256), lds, a);
+            break;
+            case 4:
+            if (occ) SSDSEG_LAUNCH_NAMED(ctx, fname, cost_bytes, cost_flops, (gemm_rowA_kernel<4, FM, 0, 0, 1, 1>), grid, dim3(256), lds, a);
+            else SSDSEG_LAUNCH_NAMED(ctx, fname, cost_bytes, cost_flops, (gemm_rowA_kernel<4, FM, 0, 0, 1, 0>), grid, dim3(256), lds, a);
+            break;
+            default:
+            if (occ) SSDSEG_LAUNCH_NAMED(ctx, fname, cost_bytes, cost_flops, (gemm_rowA_kernel<5, FM, 0, 0, 1, 1>), grid, dim3(256), lds, a);
+            else SSDSEG_LAUNCH_NAMED(ctx, fname, cost_bytes, cost_flops, (gemm_rowA_kernel<5, FM, 0, 0, 1, 0>), grid, dim3(256), lds, a);
+            break;
         }
         SSDSEG_LAUNCH_CHECK();
         return 0;
     }
-    snprintf(kbuf, sizeof(kbuf), "gemm_rowA_kernel<%d, %d, %d, 0, 0>", wn, MODE, LD);   // = the symbol rocprofv3 shows
+    snprintf(kbuf, sizeof(kbuf), "gemm_rowA_kernel<%d, %d, %d, 0, 0, %d>", wn, MODE, LD, (int)occ);   // = the symbol rocprofv3 shows
     const char* kname = ctx->timing ? ssdseg_intern(kbuf) : "";
     switch (wn) {
-        case 1: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, MODE, LD>), grid, dim3(256), lds, a); break;
-        case 2: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<2, MODE, LD>), grid, dim3(256), lds, a); break;
-        case 3: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<3, MODE, LD>), grid, dim3(256), lds, a); break;
-        case 4: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<4, MODE, LD>), grid, dim3(256), lds, a); break;
-        default: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<5, MODE, LD>), grid, dim3(256), lds, a); break;
+        case 1:
+            if (occ) SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, MODE, LD, 0, 0, 1>), grid, dim3(256), lds, a);
+            else SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, MODE, LD, 0, 0, 0>), grid, dim3(256), lds, a);
+            break;
+        case 2:
+            if (occ) SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<2, MODE, LD, 0, 0, 1>), grid, dim3(256), lds, a);
+            else SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<2, MODE, LD, 0, 0, 0>), grid, dim3(256), lds, a);
+            break;
+        case 3:
+            if (occ) SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<3, MODE, LD, 0, 0, 1>), grid, dim3(256), lds, a);
+            else SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<3, MODE, LD, 0, 0, 0>), grid, dim3(256), lds, a);
+            break;
+        case 4:
+            if (occ) SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<4, MODE, LD, 0, 0, 1>), grid, dim3(256), lds, a);
+            else SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<4, MODE, LD, 0, 0, 0>), grid, dim3(256), lds, a);
+            break;
+        default:
+            if (occ) SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<5, MODE, LD, 0, 0, 1>), grid, dim3(256), lds, a);
+            else SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<5, MODE, LD, 0, 0, 0>), grid, dim3(256), lds, a);
+            break;
     }
     SSDSEG_LAUNCH_CHECK();
     if (splits > 1) {
@@ -1074,16 +1110,35 @@ int ssdseg_pwconv_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssd
         }
         return ssdseg_colsum(ctx, a.wpart, gy, (long long)k * n, dw);
     }
+    const bool occ = a.I >= ROWA_OCC_ROWS;
     char fbuf[64];
-    snprintf(fbuf, sizeof(fbuf), "gemm_rowA_kernel<1, 1, 0, %d, 0>", nt > 6 ? 6 : nt);   // NT > 0: fused dW
+    snprintf(fbuf, sizeof(fbuf), "gemm_rowA_kernel<1, 1, 0, %d, 0, %d>", nt > 6 ? 6 : nt, (int)occ);   // NT > 0: fused dW
     const char* kname = ctx->timing ? ssdseg_intern(fbuf) : "";
     switch (nt) {
-        case 1: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 1>), grid, dim3(256), lds, a); break;
-        case 2: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 2>), grid, dim3(256), lds, a); break;
-        case 3: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 3>), grid, dim3(256), lds, a); break;
-        case 4: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 4>), grid, dim3(256), lds, a); break;
-        case 5: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 5>), grid, dim3(256), lds, a); break;
-        default: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 6>), grid, dim3(256), lds, a); break;
+        case 1:
+            if (occ) SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 1, 0, 1>), grid, dim3(256), lds, a);
+            else SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 1, 0, 0>), grid, dim3(256), lds, a);
+            break;
+        case 2:
+            if (occ) SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 2, 0, 1>), grid, dim3(256), lds, a);
+            else SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 2, 0, 0>), grid, dim3(256), lds, a);
+            break;
+        case 3:
+            if (occ) SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 3, 0, 1>), grid, dim3(256), lds, a);
+            else SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 3, 0, 0>), grid, dim3(256), lds, a);
+            break;
+        case 4:
+            if (occ) SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 4, 0, 1>), grid, dim3(256), lds, a);
+            else SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 4, 0, 0>), grid, dim3(256), lds, a);
+            break;
+        case 5:
+            if (occ) SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 5, 0, 1>), grid, dim3(256), lds, a);
+            else SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 5, 0, 0>), grid, dim3(256), lds, a);
+            break;
+        default:
+            if (occ) SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 6, 0, 1>), grid, dim3(256), lds, a);
+            else SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 6, 0, 0>), grid, dim3(256), lds, a);
+            break;
     }
     SSDSEG_LAUNCH_CHECK();
     if (gy == 1) {
@@ -1146,15 +1201,31 @@ int ssdseg_pwconv_bwd_bn(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const 
     if (cs > lds) lds = cs;
     const double cost_bytes = 4.0 * ((dy->scale != nullptr ? 2.0 : 1.0) * m * n + 2.0 * m * k + (double)k * n);
     const double cost_flops = 2.0 * m * k * n;
+    const bool occ = m >= ROWA_OCC_ROWS;
     char kbuf[64];
-    snprintf(kbuf, sizeof(kbuf), "gemm_rowA_kernel<%d, 1, 0, 0, 2>", wn);
+    snprintf(kbuf, sizeof(kbuf), "gemm_rowA_kernel<%d, 1, 0, 0, 2, %d>", wn, (int)occ);
     const char* kname = ctx->timing ? ssdseg_intern(kbuf) : "";
     switch (wn) {
-        case 1: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 0, 2>), grid, dim3(256), lds, a); break;
-        case 2: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<2, 1, 0, 0, 2>), grid, dim3(256), lds, a); break;
-        case 3: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<3, 1, 0, 0, 2>), grid, dim3(256), lds, a); break;
-        case 4: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<4, 1, 0, 0, 2>), grid, dim3(256), lds, a); break;
-        default: SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<5, 1, 0, 0, 2>), grid, dim3(256), lds, a); break;
+        case 1:
+            if (occ) SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 0, 2, 1>), grid, dim3(256), lds, a);
+            else SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<1, 1, 0, 0, 2, 0>), grid, dim3(256), lds, a);
+            break;
+        case 2:
+            if (occ) SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<2, 1, 0, 0, 2, 1>), grid, dim3(256), lds, a);
+            else SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<2, 1, 0, 0, 2, 0>), grid, dim3(256), lds, a);
+            break;
+        case 3:
+            if (occ) SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<3, 1, 0, 0, 2, 1>), grid, dim3(256), lds, a);
+            else SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<3, 1, 0, 0, 2, 0>), grid, dim3(256), lds, a);
+            break;
+        case 4:
+            if (occ) SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<4, 1, 0, 0, 2, 1>), grid, dim3(256), lds, a);
+            else SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<4, 1, 0, 0, 2, 0>), grid, dim3(256), lds, a);
+            break;
+        default:
+            if (occ) SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<5, 1, 0, 0, 2, 1>), grid, dim3(256), lds, a);
+            else SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (gemm_rowA_kernel<5, 1, 0, 0, 2, 0>), grid, dim3(256), lds, a);
+            break;
     }
     SSDSEG_LAUNCH_CHECK();
     return ssdseg_bn_bwd_finalize_launch(ctx, a.bnpart, nparts, k, (double)m, in->scale, in_mean, in_invstd, in_dgamma, in_dbeta, in_k1, in_k0);

@@ -13,7 +13,7 @@
 #pragma once
 
 template <int WN, int MODE, int NT>
-__global__ void __launch_bounds__(256) gemm_wres_kernel(RowAArgs p) {
+__global__ void __launch_bounds__(256, 2) gemm_wres_kernel(RowAArgs p) {   // two blocks per CU: see rowa_min_waves
     constexpr bool FUSEW = NT > 0;
     static_assert(!FUSEW || (MODE == 1 && WN == 1), "fused dW only for backward-data with one column tile");
     constexpr int BN = 32 * WN;
