@@ -386,23 +386,30 @@ int dw_bwd_impl(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, const ss
     const double cost_bytes = 4.0 * (2.0 * n * h * wdt * c + (dy->scale != nullptr ? 2.0 : 1.0) * n * g.ho * g.wo * c + 18.0 * c);
     const double cost_flops = 36.0 * n * g.ho * g.wo * c;
     const int choice = dw_bwd_choice();
-    const bool march_ok = dilation == 1 && stride == 1 && (long long)n * h * wdt * c < (1LL << 30);   // 32-bit byte offsets
+    // atrous (stride 1, SAME: pad == dilation): dilation^2 interleaved dense convs through the same marching kernel
+    // (SSDSEG_DW_ATROUS=gather keeps the direct-gather kernel: nine two-tensor gathers per output pixel, 0.5 TB/s)
+    const char* atr = getenv("SSDSEG_DW_ATROUS");
+    const bool atrous_march = dilation > 1 && !(atr != nullptr && !strcmp(atr, "gather")) && g.pt == dilation && g.pl == dilation &&
+                              g.ho == h && g.wo == wdt;
+    const bool march_ok = (dilation == 1 || atrous_march) && stride == 1 && (long long)n * h * wdt * c < (1LL << 30);   // 32-bit byte offsets
     if (bn_done) *bn_done = false;
     if (march_ok && (choice == 0 || choice == 1)) {
         MarchGeom mg;
-        const MarchLaunch ml = march_geometry(n, h, wdt, c, &mg);
+        const MarchLaunch ml = march_geometry(n, h, wdt, c, &mg, dilation);
         const int nparts = (int)ml.grid.x;
-        const bool fuse = bn != nullptr && !accumulate;
+        const bool fuse = bn != nullptr && !accumulate && dilation == 1;
         void* ws;
         int rc = ssdseg_workspace(ctx, (size_t)nparts * 11 * c * sizeof(float), &ws);
         if (rc) return rc;
         float* part = (float*)ws;
         float* bnpart = part + (size_t)nparts * 9 * c;
-        const bool wfull = wdt % MTW == 0;
-#define DW_BWD_MARCH(BN_, WF_, AC_)                                                                                                              \
-    SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_bwd_march_kernel<BN_, WF_, AC_>), ml.grid, ml.block, ml.lds, mg, v, w, gv, dx, part, accumulate, \
+        const bool wfull = wdt % MTW == 0 && dilation == 1;
+#define DW_BWD_MARCH(BN_, WF_, AC_, ...)                                                                                                         \
+    SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_bwd_march_kernel<BN_, WF_, AC_, ##__VA_ARGS__>), ml.grid, ml.block, ml.lds, mg, v, w, gv, dx, part, accumulate, \
                   fuse ? bn->mean : (const float*)nullptr, fuse ? bn->invstd : (const float*)nullptr, fuse ? bnpart : (float*)nullptr)
-        if (fuse && wfull) DW_BWD_MARCH(true, true, false);        // (the fused BN sums imply a sole consumer: never accumulating)
+        if (dilation > 1 && accumulate) DW_BWD_MARCH(false, false, true, true);
+        else if (dilation > 1) DW_BWD_MARCH(false, false, false, true);
+        else if (fuse && wfull) DW_BWD_MARCH(true, true, false);        // (the fused BN sums imply a sole consumer: never accumulating)
         else if (fuse) DW_BWD_MARCH(true, false, false);
         else if (wfull && accumulate) DW_BWD_MARCH(false, true, true);
         else if (wfull) DW_BWD_MARCH(false, true, false);

@@ -28,8 +28,11 @@ struct MarchGeom {
     int wstrips;   // ceil(w / MTW)
     int cb;        // channels per block (<= 256)
     int spb;       // strips per block
-    int sblocks;   // spatial blocks = n * chunks * ceil(wstrips / spb)
+    int sblocks;   // spatial blocks = n * dil^2 * chunks * ceil(wstrips / spb)
     int sgroups;   // ceil(wstrips / spb)
+    int dil;       // dilation (DIL kernels): the conv splits into dil^2 independent dense 3x3 convs over the sub-grids
+                   // (row % dil, col % dil) -- taps at +-dil are neighbours at +-1 there; rows / wstrips then refer to the
+                   // LARGEST sub-grid (ceil(h/dil) x ceil(w/dil)), smaller ones leave their surplus strips / rows idle
 };
 
 __device__ __forceinline__ float ldg_b(const float* base, unsigned byte_off) {
@@ -42,7 +45,8 @@ struct MarchStage {   // raw loads of one step: dy row i+1 (g, y) and x row i
 
 // WFULL: w % MTW == 0, the four owned columns always exist (only the two halo columns are conditional)
 // ACC: dx += result (fan-out taps) -- a template flag, not a run-time branch around every store
-template <bool BNFUSE, bool WFULL, bool ACC>
+// DIL: atrous conv as dil^2 interleaved dense convs (see MarchGeom::dil); same march, strided addressing
+template <bool BNFUSE, bool WFULL, bool ACC, bool DIL = false>
 __global__ void __launch_bounds__(MARCH_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) dw_bwd_march_kernel(MarchGeom gm, ViewDev in, const float* __restrict__ wgt, GViewDev dy,
                                                             float* __restrict__ dx, float* __restrict__ dwpart, int /*accumulate*/,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -55,10 +59,17 @@ __global__ void __launch_bounds__(MARCH_MAX_THREADS) __attribute__((amdgpu_waves
     // spatial block -> (image, row chunk, strip group)
     int sb = bpos.x;
     const int sg = sb % gm.sgroups; sb /= gm.sgroups;
-    const int rc = sb % gm.chunks;
-    const int img = sb / gm.chunks;
+    const int rc = sb % gm.chunks; sb /= gm.chunks;
+    // sub-grid (ga, gb) of a dilated conv: its own height / width, origin and strides; the dense conv is the 1x1 case
+    const int dil = DIL ? gm.dil : 1;
+    const int sub = DIL ? sb % (dil * dil) : 0;
+    const int img = DIL ? sb / (dil * dil) : sb;
+    const int ga = sub / dil, gb = sub - ga * dil;
+    const int hh = DIL ? (gm.h - ga + dil - 1) / dil : gm.h;
+    const int ww = DIL ? (gm.w - gb + dil - 1) / dil : gm.w;
     const int ws = sg * gm.spb + sp;
-    const bool active = sp < gm.spb && ch < gm.c && ws < gm.wstrips && bpos.x < gm.sblocks;
+    const bool active = sp < gm.spb && ch < gm.c && ws < gm.wstrips && bpos.x < gm.sblocks &&
+                        (!DIL || (ws * MTW < ww && rc * gm.rows < hh));
     const int chs = ch < gm.c ? ch : 0;   // safe channel for clamped addresses
 
     const bool iaff = in.scale != nullptr, gaff = dy.scale != nullptr;
@@ -82,21 +93,23 @@ __global__ void __launch_bounds__(MARCH_MAX_THREADS) __attribute__((amdgpu_waves
     if (active) {
         const int w0 = ws * MTW;
         const int r0 = rc * gm.rows;
-        const int r1 = r0 + gm.rows < gm.h ? r0 + gm.rows : gm.h;
+        const int r1 = r0 + gm.rows < hh ? r0 + gm.rows : hh;
         // 32-bit BYTE offsets from the (uniform) tensor bases: the launcher guarantees n*h*w*c*4 < 2^32
-        const unsigned ibase = (((unsigned)img * gm.h * gm.w) * gm.c + ch) * 4u;   // element (row, col) at ibase + (row*w + col)*c*4
-        const unsigned rstride = (unsigned)gm.w * gm.c * 4u;
+        // element (row, col) of the sub-grid at ibase + row*rstride + col*cstride
+        const unsigned ibase = ((((unsigned)img * gm.h + ga) * gm.w + gb) * gm.c + ch) * 4u;
+        const unsigned rstride = (unsigned)dil * gm.w * gm.c * 4u;
+        const unsigned cstride = (unsigned)dil * gm.c * 4u;
         bool cok[MWC];
         unsigned coff[MWC];
 #pragma unroll
         for (int a = 0; a < MWC; ++a) {
             const int col = w0 - 1 + a;
-            cok[a] = (WFULL && a >= 1 && a <= MTW) ? true : (col >= 0 && col < gm.w);
-            coff[a] = (unsigned)(cok[a] ? col : 0) * gm.c * 4u;
+            cok[a] = (WFULL && a >= 1 && a <= MTW) ? true : (col >= 0 && col < ww);
+            coff[a] = (unsigned)(cok[a] ? col : 0) * cstride;
         }
         // issue the raw loads of one step: dy row `drow` (clamped into the image; masked later) and x row `xrow` (always valid)
         auto issue = [&](int drow, int xrow, MarchStage& s) {
-            const int dclamp = drow < 0 ? 0 : (drow >= gm.h ? gm.h - 1 : drow);
+            const int dclamp = drow < 0 ? 0 : (drow >= hh ? hh - 1 : drow);
             const unsigned db = ibase + (unsigned)dclamp * rstride, xb = ibase + (unsigned)xrow * rstride;
 #pragma unroll
             for (int a = 0; a < MWC; ++a) {
@@ -107,7 +120,7 @@ __global__ void __launch_bounds__(MARCH_MAX_THREADS) __attribute__((amdgpu_waves
         };
         auto make_dy = [&](int row, const float (&g)[MWC], const float (&y)[MWC], float (&d)[MWC]) {
             // a row outside the image contributes nothing: fold that into the three per-row coefficients instead of six selects
-            const bool rok = row >= 0 && row < gm.h;
+            const bool rok = row >= 0 && row < hh;
             const float gsr = rok ? gs : 0.f, k1r = rok ? gk1 : 0.f, k0r = rok ? gk0 : 0.f;
 #pragma unroll
             for (int a = 0; a < MWC; ++a) {
@@ -236,8 +249,11 @@ inline void march_split(int c, int wstrips, int* cb_out, int* spb_out, int* cchu
 
 // geometry for an n x h x w x c tensor: channel chunks of <= 256, as many strips per block as fit in 256 threads, row chunks
 // sized so that the launch has >= ~4096 waves (16 per CU) where the layer is big enough
-inline MarchLaunch march_geometry(int n, int h, int w, int c, MarchGeom* g) {
-    g->n = n; g->h = h; g->w = w; g->c = c;
+inline MarchLaunch march_geometry(int n, int h, int w, int c, MarchGeom* g, int dil = 1) {
+    g->n = n; g->h = h; g->w = w; g->c = c; g->dil = dil;
+    const int subs = dil * dil;
+    h = cdiv(h, dil); w = cdiv(w, dil);   // the largest sub-grid
+    n *= subs;
     g->wstrips = cdiv(w, MTW);
     int cchunks;
     march_split(c, g->wstrips, &g->cb, &g->spb, &cchunks);

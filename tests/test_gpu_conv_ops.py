@@ -56,6 +56,9 @@ DW_CASES = [
     (1, 9, 8, 8, 2, 1),        # pads (1,1)/(0,1)
     (2, 30, 40, 64, 1, 3),     # atrous
     (1, 30, 40, 32, 1, 12),
+    (1, 30, 40, 576, 1, 6),    # the ASPP shape: 36 interleaved 5x7 sub-grids, three 192-channel chunks
+    (2, 7, 5, 8, 1, 3),        # ragged sub-grids (3x2, 2x2, 2x1 ...)
+    (1, 4, 5, 8, 1, 12),       # dilation > image: every sub-grid is one pixel, only the centre tap lands
     (1, 5, 6, 1284, 1, 1),     # > 256 channel vectors (grid.y = 2)
     (1, 1, 1, 4, 1, 1),
 ]
