@@ -22,8 +22,11 @@ int ew_blocks(long long total, int threads = 256) {
 
 // ------------------------------------------------------------------------------------------------ GAP
 // one block per (image, 64-channel-vector group); threads (cv, y) walk the pixels, fixed-order reduction over y
-__global__ void __launch_bounds__(512) gap_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
-                                                      int act, float* __restrict__ out, int hw, int c) {
+// Sum over the `hw` pixels of "image" blockIdx.x (= one of the `chunks` equal slices of a real image when the caller splits
+// the reduction so that n * chunks blocks fill the chip): out[blockIdx.x][c] = mul * sum_p act(s*x + t).  x rows are `ldx` apart.
+__global__ void __launch_bounds__(512) gap_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, int act, float* __restrict__ out, int hw, int c,
+                                                      float mul) {
     extern __shared__ float4 red[];
     const int cv = c / 4;
     const int cvi = blockIdx.y * blockDim.x + threadIdx.x;
@@ -33,16 +36,57 @@ __global__ void __launch_bounds__(512) gap_fwd_kernel(const float* __restrict__ 
     if (cvi < cv) {
         float4 s = f4(0.f), t = f4(0.f);
         if (aff) { s = ld4(scale + cvi * 4); t = ld4(shift + cvi * 4); }
-        for (int p = threadIdx.y; p < hw; p += blockDim.y) add4(acc, view_apply4(ld4(x + ((long long)n * hw + p) * c + cvi * 4), s, t, aff, act));
+        for (int p = threadIdx.y; p < hw; p += blockDim.y) add4(acc, view_apply4(ld4(x + ((long long)n * hw + p) * ldx + cvi * 4), s, t, aff, act));
     }
     red[threadIdx.y * blockDim.x + threadIdx.x] = acc;
     __syncthreads();
     if (threadIdx.y == 0 && cvi < cv) {
         float4 r = f4(0.f);
         for (int y = 0; y < (int)blockDim.y; ++y) add4(r, red[y * blockDim.x + threadIdx.x]);
-        const float inv = 1.f / (float)hw;
-        st4(out + (long long)n * c + cvi * 4, make_float4(r.x * inv, r.y * inv, r.z * inv, r.w * inv));
+        st4(out + (long long)n * c + cvi * 4, make_float4(r.x * mul, r.y * mul, r.z * mul, r.w * mul));
     }
+}
+
+// second stage of a split pixel sum: out[n][.] (row stride ldo) = sum_k part[n][k][.] in fixed order (+ previous contents)
+__global__ void chunk_sum_kernel(const float* __restrict__ part, int chunks, int cv, float* __restrict__ out, int ldo, int n, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * cv) return;
+    const int img = i / cv, c4 = i - img * cv;
+    float4 r = f4(0.f);
+    for (int k = 0; k < chunks; ++k) add4(r, ld4(part + ((long long)(img * chunks + k) * cv + c4) * 4));
+    float* o = out + (long long)img * ldo + c4 * 4;
+    if (accumulate) add4(r, ld4(o));
+    st4(o, r);
+}
+
+// host side of the (optionally split) pixel sum: out[n][c] (row stride ldo) = mul * sum over the hw pixels of each image
+int pixel_sum(ssdseg_ctx* ctx, const float* x, int ldx, const float* scale, const float* shift, int act, float* out, int ldo, int n, int hw,
+              int c, float mul, int accumulate, double cost_bytes) {
+    const int cv = c / 4;
+    const int bx = cv < 128 ? cv : 128;
+    int chunks = 1;   // equal slices only (deterministic, no ragged tail): the largest divisor of hw that still leaves >= 64 pixels
+    for (int k = 16; k >= 2; --k)
+        if (hw % k == 0 && hw / k >= 64 && n * k <= 1024) { chunks = k; break; }
+    const int hwc = hw / chunks;
+    int by = 512 / bx;
+    if (by > hwc) by = hwc;
+    if (by < 1) by = 1;
+    if (chunks == 1 && !accumulate && ldo == c) {
+        SSDSEG_LAUNCH(ctx, cost_bytes, 0.0, gap_fwd_kernel, dim3(n, cdiv(cv, bx)), dim3(bx, by), (size_t)bx * by * sizeof(float4), x, ldx, scale,
+                      shift, act, out, hw, c, mul);
+        SSDSEG_LAUNCH_CHECK();
+        return 0;
+    }
+    void* ws;
+    int rc = ssdseg_workspace(ctx, (size_t)n * chunks * c * sizeof(float), &ws);
+    if (rc) return rc;
+    SSDSEG_LAUNCH(ctx, cost_bytes, 0.0, gap_fwd_kernel, dim3(n * chunks, cdiv(cv, bx)), dim3(bx, by), (size_t)bx * by * sizeof(float4), x, ldx,
+                  scale, shift, act, (float*)ws, hwc, c, mul);
+    SSDSEG_LAUNCH_CHECK();
+    SSDSEG_LAUNCH(ctx, 4.0 * n * (chunks + 1) * c, 0.0, chunk_sum_kernel, dim3(cdiv(n * cv, 256)), dim3(256), 0, (const float*)ws, chunks, cv, out,
+                  ldo, n, accumulate);
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
 }
 
 __global__ void gap_bwd_kernel(const float* __restrict__ g, float* __restrict__ dx, int n, int hw, int cv, int accumulate) {
@@ -287,15 +331,8 @@ int ssdseg_gap_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, float* out, int n, in
     SSDSEG_ARG(n > 0, 4);
     SSDSEG_ARG(hw > 0, 5);
     SSDSEG_ARG(c > 0 && c % 4 == 0, 6);
-    const int cv = c / 4;
-    const int bx = cv < 128 ? cv : 128;
-    int by = 512 / bx;
-    if (by > hw) by = hw;
-    if (by < 1) by = 1;
-    SSDSEG_LAUNCH(ctx, 4.0 * ((double)n * hw * c + (double)n * c), 0.0, gap_fwd_kernel, dim3(n, cdiv(cv, bx)), dim3(bx, by),
-                  (size_t)bx * by * sizeof(float4), in->x, in->scale, in->shift, in->act, out, hw, c);
-    SSDSEG_LAUNCH_CHECK();
-    return 0;
+    return pixel_sum(ctx, in->x, c, in->scale, in->shift, in->act, out, c, n, hw, c, 1.f / (float)hw, 0,
+                     4.0 * ((double)n * hw * c + (double)n * c));
 }
 
 int ssdseg_gap_bwd(ssdseg_ctx* ctx, const float* g, float* dx, int n, int hw, int c, int accumulate) {
@@ -338,6 +375,9 @@ int ssdseg_bilinear_bwd(ssdseg_ctx* ctx, const float* g, int ldg, float* dx, int
     SSDSEG_ARG(n > 0 && h > 0 && wdt > 0, 6);
     SSDSEG_ARG(c > 0 && c % 4 == 0, 9);
     SSDSEG_ARG(fy >= 1 && fx >= 1, 10);
+    if (h == 1 && wdt == 1)   // a 1x1 source feeds every output pixel with weight 1 (the ASPP pooling branch): a plain pixel sum
+        return pixel_sum(ctx, g, ldg, nullptr, nullptr, SSDSEG_ACT_NONE, dx, ldx, n, fy * fx, c, 1.f, accumulate,
+                         4.0 * ((double)n * c * (1 + fy * fx)));
     const long long total = (long long)n * h * wdt * (c / 4);
     SSDSEG_LAUNCH(ctx, 4.0 * ((double)n * h * wdt * c * (1 + fy * fx)), 0.0, bilinear_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, g, ldg,
                   dx, ldx, n, h, wdt, c / 4, fy, fx, accumulate);

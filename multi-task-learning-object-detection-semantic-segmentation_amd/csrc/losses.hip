@@ -105,51 +105,90 @@ __global__ void det_image_stats_kernel(const float* __restrict__ partial, int nb
     img_stats[i] = s;
 }
 
-// ---- exact top-k (single block: n is a few 1e5, four 8-bit radix passes + one ordered tie pass)
-constexpr int TK_THREADS = 1024;
-__global__ void __launch_bounds__(TK_THREADS) topk_mask_kernel(const float* __restrict__ v, int n, int k_host, const int* __restrict__ counts,
-                                                               unsigned char* __restrict__ mask) {
-    __shared__ int hist[256];
-    __shared__ unsigned s_prefix;
-    __shared__ int s_krem;
-    __shared__ int scan[TK_THREADS];
+// ---- exact top-k over a few 1e5 values: MSB-first radix select (four 8-bit passes) + one ordered tie pass, every pass a
+// multi-block kernel.  All cross-block traffic is integer (histogram counts, equal-element counts), so the result does not
+// depend on scheduling: mask[i] = 1 for the k largest values, ties at the k-th value resolved lowest index first.
+constexpr int TK_THREADS = 256;
+constexpr int TK_MAXB = 512;
+struct TopkState {
+    int hist[4][256];   // hist[p][b]: keys matching the prefix chosen by passes < p whose byte p (from the top) is b
+    int eq[TK_MAXB];    // per block of the tie pass: elements equal to the k-th key inside the block's index range
+};
+
+__device__ __forceinline__ int topk_k(int k_host, const int* __restrict__ counts) {
+    if (counts == nullptr) return k_host;
+    const int nbg = counts[0], npos = counts[1];   // mining: k = min(3 * #positives, #background)  (losses.py:113)
+    return nbg == 0 ? 0 : min(3 * npos, nbg);
+}
+
+// Every block re-derives the selection from the finished histograms of the earlier passes (256 ints each: cheaper than a
+// one-block kernel between passes): prefix = the top 8*npass bits of the k-th largest key, krem = its rank inside that bucket.
+__device__ __forceinline__ void topk_select(const TopkState* __restrict__ st, int npass, int k, int* lh, unsigned* s_prefix, int* s_krem) {
     const int t = threadIdx.x;
-    int k = k_host;
-    if (counts != nullptr) {                       // mining: k = min(3 * #positives, #background)  (losses.py:113)
-        const int nbg = counts[0], npos = counts[1];
-        k = nbg == 0 ? 0 : min(3 * npos, nbg);
-    }
-    if (k <= 0 || k >= n) {
-        for (int i = t; i < n; i += TK_THREADS) mask[i] = (k >= n && k > 0) ? 1 : 0;
-        return;
-    }
-    if (t == 0) { s_prefix = 0u; s_krem = k; }
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        if (t < 256) hist[t] = 0;
+    if (t == 0) { *s_prefix = 0u; *s_krem = k; }
+    for (int p = 0; p < npass; ++p) {
         __syncthreads();
-        const unsigned prefix = s_prefix;
-        const unsigned himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
-        for (int i = t; i < n; i += TK_THREADS) {
-            const unsigned key = order_key(v[i]);
-            if ((key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
-        }
+        lh[t] = st->hist[p][t];
         __syncthreads();
         if (t == 0) {
-            int krem = s_krem, bin = 255;
+            int krem = *s_krem, bin = 255;
             for (; bin > 0; --bin) {
-                if (hist[bin] >= krem) break;
-                krem -= hist[bin];
+                if (lh[bin] >= krem) break;
+                krem -= lh[bin];
             }
-            s_prefix = prefix | ((unsigned)bin << shift);
-            s_krem = krem;
+            *s_prefix |= (unsigned)bin << (24 - 8 * p);
+            *s_krem = krem;
         }
-        __syncthreads();
     }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(TK_THREADS) topk_hist_kernel(const float* __restrict__ v, int n, int k_host, const int* __restrict__ counts,
+                                                               TopkState* __restrict__ st, int pass) {
+    __shared__ int lh[256];
+    __shared__ int bins[256];
+    __shared__ unsigned s_prefix;
+    __shared__ int s_krem;
+    const int t = threadIdx.x;
+    const int k = topk_k(k_host, counts);
+    if (k <= 0 || k >= n) return;   // uniform: the mask kernel handles the trivial cases
+    topk_select(st, pass, k, lh, &s_prefix, &s_krem);
+    const unsigned prefix = s_prefix;
+    const int shift = 24 - 8 * pass;
+    const unsigned himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+    bins[t] = 0;
+    __syncthreads();
+    for (int i = blockIdx.x * TK_THREADS + t; i < n; i += gridDim.x * TK_THREADS) {
+        const unsigned key = order_key(v[i]);
+        if ((key & himask) == prefix) atomicAdd(&bins[(key >> shift) & 255u], 1);
+    }
+    __syncthreads();
+    if (bins[t] != 0) atomicAdd(&st->hist[pass][t], bins[t]);
+}
+
+// tie pass: block b owns the contiguous index range [b*chunk, (b+1)*chunk), thread t a contiguous slice of it
+// PHASE 0: count the elements equal to the k-th key per block; PHASE 1: write the mask
+template <int PHASE>
+__global__ void __launch_bounds__(TK_THREADS) topk_tie_kernel(const float* __restrict__ v, int n, int k_host, const int* __restrict__ counts,
+                                                              TopkState* __restrict__ st, unsigned char* __restrict__ mask) {
+    __shared__ int lh[256];
+    __shared__ int scan[TK_THREADS];
+    __shared__ unsigned s_prefix;
+    __shared__ int s_krem;
+    const int t = threadIdx.x;
+    const int chunk = (n + gridDim.x - 1) / gridDim.x;
+    const int b0 = min(n, (int)blockIdx.x * chunk), b1 = min(n, b0 + chunk);
+    const int k = topk_k(k_host, counts);
+    if (k <= 0 || k >= n) {
+        if (PHASE == 1)
+            for (int i = b0 + t; i < b1; i += TK_THREADS) mask[i] = (k >= n && k > 0) ? 1 : 0;
+        return;
+    }
+    topk_select(st, 4, k, lh, &s_prefix, &s_krem);
     const unsigned kth = s_prefix;     // key of the k-th largest element
     const int take_equal = s_krem;     // how many elements equal to it are selected, lowest indices first
-    const int chunk = (n + TK_THREADS - 1) / TK_THREADS;
-    const int i0 = min(n, t * chunk), i1 = min(n, i0 + chunk);
+    const int sub = (b1 - b0 + TK_THREADS - 1) / TK_THREADS;
+    const int i0 = min(b1, b0 + t * sub), i1 = min(b1, i0 + sub);
     int eq = 0;
     for (int i = i0; i < i1; ++i) eq += order_key(v[i]) == kth;
     scan[t] = eq;
@@ -160,13 +199,43 @@ __global__ void __launch_bounds__(TK_THREADS) topk_mask_kernel(const float* __re
         scan[t] += add;
         __syncthreads();
     }
-    int rank = scan[t] - eq;           // equal elements before this thread's chunk
+    if (PHASE == 0) {
+        if (t == TK_THREADS - 1) st->eq[blockIdx.x] = scan[t];
+        return;
+    }
+    int before = 0;                    // equal elements in the blocks in front of this one
+    for (int q = t; q < (int)blockIdx.x; q += TK_THREADS) before += st->eq[q];
+    __syncthreads();
+    lh[t] = before;
+    __syncthreads();
+    for (int off = TK_THREADS / 2; off > 0; off >>= 1) {
+        if (t < off) lh[t] += lh[t + off];
+        __syncthreads();
+    }
+    int rank = lh[0] + scan[t] - eq;   // equal elements before this thread's slice
     for (int i = i0; i < i1; ++i) {
         const unsigned key = order_key(v[i]);
         unsigned char m = key > kth;
         if (key == kth) { m = rank < take_equal; ++rank; }
         mask[i] = m;
     }
+}
+
+// host side: `state` = TopkState scratch (device), zeroed here
+int topk_mask_launch(ssdseg_ctx* ctx, const float* v, int n, int k_host, const int* counts, TopkState* state, unsigned char* mask) {
+    SSDSEG_HIP(hipMemsetAsync(state, 0, sizeof(TopkState), ctx->stream));
+    int nb = cdiv(n, TK_THREADS * 4);
+    if (nb > TK_MAXB) nb = TK_MAXB;
+    if (nb < 1) nb = 1;
+    for (int pass = 0; pass < 4; ++pass) {
+        SSDSEG_LAUNCH(ctx, 4.0 * n, 0.0, topk_hist_kernel, dim3(nb), dim3(TK_THREADS), 0, v, n, k_host, counts, state, pass);
+        SSDSEG_LAUNCH_CHECK();
+    }
+    SSDSEG_LAUNCH(ctx, 4.0 * n, 0.0, topk_tie_kernel<0>, dim3(nb), dim3(TK_THREADS), 0, v, n, k_host, counts, state, mask);
+    SSDSEG_LAUNCH_CHECK();
+    SSDSEG_LAUNCH(ctx, 5.0 * n, 0.0, topk_tie_kernel<1>, dim3(nb), dim3(TK_THREADS), 0, v, n, k_host, counts, state, mask);
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
 }
 
 // pass 2: gradients and the kept-background loss
@@ -264,9 +333,10 @@ int ssdseg_topk_mask(ssdseg_ctx* ctx, const float* values, int n, int k, uint8_t
     SSDSEG_ARG(n > 0, 3);
     SSDSEG_ARG(k >= 0, 4);
     SSDSEG_ARG(mask != nullptr, 5);
-    SSDSEG_LAUNCH(ctx, 5.0 * 4.0 * n, 0.0, topk_mask_kernel, dim3(1), dim3(TK_THREADS), 0, values, n, k, (const int*)nullptr, mask);
-    SSDSEG_LAUNCH_CHECK();
-    return 0;
+    void* ws;
+    int rc = ssdseg_workspace(ctx, sizeof(TopkState), &ws);
+    if (rc) return rc;
+    return topk_mask_launch(ctx, values, n, k, nullptr, (TopkState*)ws, mask);
 }
 
 int ssdseg_det_loss(ssdseg_ctx* ctx, const float* y_labels, const float* p_labels, const float* y_boxes, const float* p_boxes, int b,
@@ -279,9 +349,9 @@ int ssdseg_det_loss(ssdseg_ctx* ctx, const float* y_labels, const float* p_label
     SSDSEG_ARG(c == 4, 8);   // quirk Q2: the reference only works with 4 classes (models.py:250-253 vs :265-268)
     const long long n = (long long)b * a;
     SSDSEG_ARG(n < (1LL << 30), 6);
-    // workspace: bgval[n] f32 | partial[b][BPI][4] | img_stats[b][4] | partial2[b][BPI] | counts[2] i32 | mask[n] u8
+    // workspace: bgval[n] f32 | partial[b][BPI][4] | img_stats[b][4] | partial2[b][BPI] | counts[2] i32 | top-k state | mask[n] u8
     const size_t o_bg = 0, o_part = o_bg + (size_t)n * 4, o_stats = o_part + (size_t)b * BPI * 16, o_p2 = o_stats + (size_t)b * 16,
-                 o_cnt = o_p2 + (size_t)b * BPI * 4, o_mask = o_cnt + 16, total = o_mask + (size_t)n;
+                 o_cnt = o_p2 + (size_t)b * BPI * 4, o_tk = o_cnt + 16, o_mask = o_tk + sizeof(TopkState), total = o_mask + (size_t)n;
     void* ws;
     int rc = ssdseg_workspace(ctx, total, &ws);
     if (rc) return rc;
@@ -299,8 +369,8 @@ int ssdseg_det_loss(ssdseg_ctx* ctx, const float* y_labels, const float* p_label
     SSDSEG_LAUNCH_CHECK();
     SSDSEG_LAUNCH(ctx, 0.0, 0.0, det_image_stats_kernel, dim3(cdiv(b * 4, 64)), dim3(64), 0, partial, BPI, b, img_stats);
     SSDSEG_LAUNCH_CHECK();
-    SSDSEG_LAUNCH(ctx, 5.0 * 4.0 * n, 0.0, topk_mask_kernel, dim3(1), dim3(TK_THREADS), 0, bgval, (int)n, 0, (const int*)counts, mask);
-    SSDSEG_LAUNCH_CHECK();
+    rc = topk_mask_launch(ctx, bgval, (int)n, 0, (const int*)counts, (TopkState*)(base + o_tk), mask);
+    if (rc) return rc;
     SSDSEG_LAUNCH(ctx, pass_bytes + 32.0 * n, 0.0, det_final_kernel, dim3(BPI, b), dim3(256), 0, y_labels, p_labels, y_boxes, p_boxes, a, mask,
                   img_stats, loss_scale, d_logits, d_boxes, partial2);
     SSDSEG_LAUNCH_CHECK();

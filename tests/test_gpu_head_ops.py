@@ -110,6 +110,15 @@ def test_bilinear(ctx, rng, n, h, w, c, fy, fx):
     dx.upload(base)
     ctx.call("ssdseg_bilinear_bwd", ctx.array(g), c, dx, c, n, h, w, c, fy, fx, 1)
     assert rel_err(dx.download(), dx_ref + base) < 1e-5
+    # the gradient arriving as a slice of a wider (concat) gradient buffer, the result leaving into one
+    gw = rng.normal(0, 1, (n * h * fy * w * fx, ldo)).astype(np.float32)
+    gw[:, 4:4 + c] = g.reshape(-1, c)
+    gbuf = ctx.array(gw)
+    dxw = ctx.zeros((n * h * w, ldo))
+    ctx.call("ssdseg_bilinear_bwd", gbuf.view(4, (gbuf.size - 4,)), ldo, dxw.view(4, (dxw.size - 4,)), ldo, n, h, w, c, fy, fx, 0)
+    got = dxw.download()
+    assert rel_err(got[:, 4:4 + c].reshape(dx_ref.shape), dx_ref) < 1e-5
+    assert np.all(got[:, :4] == 0) and np.all(got[:, 4 + c:] == 0)
 
 
 def test_mask_head(ctx, rng):
@@ -153,7 +162,8 @@ def test_head_gather_and_softmax(ctx, rng):
     assert np.abs(sm.download() - O.softmax(got)).max() < 1e-6
 
 
-@pytest.mark.parametrize("n,k", [(1000, 0), (1000, 1), (5000, 1234), (307200, 2700), (4096, 4095), (4096, 4096), (10, 50)])
+@pytest.mark.parametrize("n,k", [(1000, 0), (1000, 1), (5000, 1234), (307200, 2700), (4096, 4095), (4096, 4096), (10, 50),
+                                 (307200, 300001), (700001, 123457), (257, 5), (1, 1)])
 def test_topk_mask_exact(ctx, rng, n, k):
     v = rng.exponential(1.0, n).astype(np.float32)
     v[rng.integers(0, n, n // 3)] = 0.0                     # plateau of ties at 0 (positives contribute 0 to the mining vector)
@@ -163,6 +173,16 @@ def test_topk_mask_exact(ctx, rng, n, k):
     mask = ctx.empty(n, np.uint8)
     ctx.call("ssdseg_topk_mask", ctx.array(v), n, k, mask)
     assert np.array_equal(mask.download(), O.topk_mask(v, min(k, n)))
+
+
+@pytest.mark.parametrize("n,k", [(307200, 1000), (5000, 4999), (300, 1)])
+def test_topk_mask_all_ties(ctx, n, k):
+    """every value equal: the selection is the k lowest indices, across block and thread boundaries of the tie pass"""
+    v = np.full(n, 0.25, np.float32)
+    mask = ctx.empty(n, np.uint8)
+    ctx.call("ssdseg_topk_mask", ctx.array(v), n, k, mask)
+    got = mask.download()
+    assert got[:k].all() and not got[k:].any()
 
 
 def make_det_case(rng, b, a, pos_frac=0.02):
