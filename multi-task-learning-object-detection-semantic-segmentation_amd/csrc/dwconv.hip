@@ -434,19 +434,20 @@ int dw_bwd_impl(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, const ss
         if (rc) return rc;
         float* part = (float*)ws;
         float* bnpart = part + (size_t)nparts * 9 * c;
-#define DW_BWD_MARCH2(BN_, PT_, PL_)                                                                                                          \
-    SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_bwd_march2_kernel<BN_, PT_, PL_>), ml.grid, ml.block, ml.lds, mg, v, w, gv, dx, part,      \
+#define DW_BWD_MARCH2(BN_, PT_, PL_, AC_)                                                                                                     \
+    SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_bwd_march2_kernel<BN_, PT_, PL_, AC_>), ml.grid, ml.block, ml.lds, mg, v, w, gv, dx, part, \
                   accumulate, fuse ? bn->mean : (const float*)nullptr, fuse ? bn->invstd : (const float*)nullptr,                          \
                   fuse ? bnpart : (float*)nullptr)
-#define DW_BWD_MARCH2_P(BN_)                             \
-    do {                                                 \
-        if (g.pt == 0 && g.pl == 0) DW_BWD_MARCH2(BN_, 0, 0); \
-        else if (g.pt == 0) DW_BWD_MARCH2(BN_, 0, 1);    \
-        else if (g.pl == 0) DW_BWD_MARCH2(BN_, 1, 0);    \
-        else DW_BWD_MARCH2(BN_, 1, 1);                   \
+#define DW_BWD_MARCH2_P(BN_, AC_)                             \
+    do {                                                      \
+        if (g.pt == 0 && g.pl == 0) DW_BWD_MARCH2(BN_, 0, 0, AC_); \
+        else if (g.pt == 0) DW_BWD_MARCH2(BN_, 0, 1, AC_);    \
+        else if (g.pl == 0) DW_BWD_MARCH2(BN_, 1, 0, AC_);    \
+        else DW_BWD_MARCH2(BN_, 1, 1, AC_);                   \
     } while (0)
-        if (fuse) DW_BWD_MARCH2_P(true);
-        else DW_BWD_MARCH2_P(false);
+        if (fuse) DW_BWD_MARCH2_P(true, false);
+        else if (accumulate && dx != nullptr) DW_BWD_MARCH2_P(false, true);
+        else DW_BWD_MARCH2_P(false, false);
 #undef DW_BWD_MARCH2_P
 #undef DW_BWD_MARCH2
         SSDSEG_LAUNCH_CHECK();

@@ -279,8 +279,10 @@ inline MarchLaunch march_geometry(int n, int h, int w, int c, MarchGeom* g, int 
 //   dx[2r-PT+1][wi0+j] =                   sum_kw dy[r       ][..] w[1 ][kw]
 //   dW[0|1][kw] += a[2r-PT+(0|1)][wi0+2q+kw] * dy[r][wo0+q],   dW[2][kw] += a[2r-PT][wi0+2q+kw] * dy[r-1][wo0+q]
 // (the kh = 2 tap of output row r-1 reads input row 2r-PT, i.e. the first row of THIS step: dy row r-1 is kept).
+template <bool ACC>
 struct March2Stage {   // raw loads of one step: dy row r (3 columns of g, y) and x rows 2r-PT, 2r-PT+1 (5 columns each)
     float g[3], y[3], x0[5], x1[5];
+    float o0[ACC ? 4 : 1], o1[ACC ? 4 : 1];   // ACC: previous contents of the 2 x 4 dx elements this step finalises
 };
 
 struct March2Geom {
@@ -288,9 +290,11 @@ struct March2Geom {
     int rows, chunks, wstrips, cb, spb, sblocks, sgroups;   // as MarchGeom, over the OUTPUT rows / 2-column output strips
 };
 
-template <bool BNFUSE, int PT, int PL>
+// ACC: dx += result.  The old values are fetched WITH the step's other loads (one step ahead); read inline at the store they
+// put a load -> add -> store round trip on every element (2.6 TB/s where the overwriting variant runs 5.4)
+template <bool BNFUSE, int PT, int PL, bool ACC = false>
 __global__ void __launch_bounds__(MARCH_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) dw_bwd_march2_kernel(March2Geom gm, ViewDev in, const float* __restrict__ wgt, GViewDev dy,
-                                                             float* __restrict__ dx, float* __restrict__ dwpart, int accumulate,
+                                                             float* __restrict__ dx, float* __restrict__ dwpart, int /*accumulate*/,
                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
                                                              float* __restrict__ bnpart) {
     extern __shared__ float mred[];   // [11][blockDim.x]
@@ -346,7 +350,7 @@ __global__ void __launch_bounds__(MARCH_MAX_THREADS) __attribute__((amdgpu_waves
             xoff[b] = (unsigned)(xok[b] ? col : 0) * gm.c * 4u;
         }
         auto clampi = [](int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); };
-        auto issue = [&](int r, March2Stage& s) {   // rows clamped into the tensors; masked when consumed
+        auto issue = [&](int r, March2Stage<ACC>& s) {   // rows clamped into the tensors; masked when consumed
             const unsigned db = obase + (unsigned)clampi(r, gm.ho - 1) * orow;
             const unsigned xb0 = ibase + (unsigned)clampi(2 * r - PT, gm.h - 1) * irow;
             const unsigned xb1 = ibase + (unsigned)clampi(2 * r - PT + 1, gm.h - 1) * irow;
@@ -359,6 +363,13 @@ __global__ void __launch_bounds__(MARCH_MAX_THREADS) __attribute__((amdgpu_waves
             for (int b = 0; b < 5; ++b) {
                 s.x0[b] = ldg_b(in.x, xb0 + xoff[b]);
                 s.x1[b] = ldg_b(in.x, xb1 + xoff[b]);
+            }
+            if (ACC) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s.o0[j] = ldg_b(dx, xb0 + xoff[j]);
+                    s.o1[j] = ldg_b(dx, xb1 + xoff[j]);
+                }
             }
         };
         auto make_dy = [&](int row, const float (&g)[3], const float (&y)[3], float (&d)[3]) {
@@ -373,11 +384,11 @@ __global__ void __launch_bounds__(MARCH_MAX_THREADS) __attribute__((amdgpu_waves
         };
         float dprev[3], dcur[3];
         {
-            March2Stage p;
+            March2Stage<ACC> p;
             issue(r0 - 1, p);
             make_dy(r0 - 1, p.g, p.y, dprev);
         }
-        auto step = [&](int r, March2Stage& cur, March2Stage& nxt) {
+        auto step = [&](int r, March2Stage<ACC>& cur, March2Stage<ACC>& nxt) {
             make_dy(r, cur.g, cur.y, dcur);
             const int hi0 = 2 * r - PT, hi1 = hi0 + 1;
             const bool rok0 = hi0 >= 0 && hi0 < gm.h, rok1 = hi1 < gm.h;   // hi1 >= 0 always
@@ -407,7 +418,7 @@ __global__ void __launch_bounds__(MARCH_MAX_THREADS) __attribute__((amdgpu_waves
                 if (rok0 && xok[j]) {
                     if (dx != nullptr) {
                         float* p = reinterpret_cast<float*>(reinterpret_cast<char*>(dx) + (ob0 + xoff[j]));
-                        if (accumulate) acc0[j] += *p;
+                        if (ACC) acc0[j] += cur.o0[j];
                         *p = acc0[j];
                     }
                     if (BNFUSE) {
@@ -419,7 +430,7 @@ __global__ void __launch_bounds__(MARCH_MAX_THREADS) __attribute__((amdgpu_waves
                 if (rok1 && xok[j]) {
                     if (dx != nullptr) {
                         float* p = reinterpret_cast<float*>(reinterpret_cast<char*>(dx) + (ob1 + xoff[j]));
-                        if (accumulate) acc1[j] += *p;
+                        if (ACC) acc1[j] += cur.o1[j];
                         *p = acc1[j];
                     }
                     if (BNFUSE) {
@@ -442,7 +453,7 @@ __global__ void __launch_bounds__(MARCH_MAX_THREADS) __attribute__((amdgpu_waves
 #pragma unroll
             for (int a = 0; a < 3; ++a) dprev[a] = dcur[a];
         };
-        March2Stage sa, sb2;
+        March2Stage<ACC> sa, sb2;
         issue(r0, sa);
         int r = r0;
         for (; r + 1 < r1; r += 2) {

@@ -811,7 +811,17 @@ int launch_rowA(ssdseg_ctx* ctx, const RowAArgs& a0) {
             if (s >= 2) splits = s;
         }
     }
-    dim3 grid(cdiv(a.J, 32 * wn), splits > 1 ? cdiv(a.I, BM) : nparts, splits);
+    // Backward-data of the 30x40-stage expand convs (38400 rows = 300 row tiles, 384-576 reduction channels of a TWO-tensor
+    // gradient view, 64-96 output columns): the default picks 32-column tiles to have 600-900 blocks, and every column tile
+    // re-reads the whole (g, y) operand from the fabric (measured 5 TB/s of L2-level reads for 1.4 TB/s algorithmic).  One
+    // column tile spanning all outputs reads it once; with >= 256 row tiles there is still a block per CU (109 -> 88 us).
+    // Not for the 15x20 stage (75 row tiles: 2x slower) and no gain for the forward (single-tensor operand).
+    int grid_y = nparts;
+    if (MODE == 1 && LD == 0 && splits == 1 && a.cs != nullptr && a.R >= 256) {
+        const int wide = cdiv(a.J, 32), mtiles = cdiv(a.I, BM);
+        if (wide > wn && wide <= 3 && mtiles >= 256 && a.I < ROWA_OCC_ROWS) { wn = wide; grid_y = mtiles < 2048 ? mtiles : 2048; }
+    }
+    dim3 grid(cdiv(a.J, 32 * wn), splits > 1 ? cdiv(a.I, BM) : grid_y, splits);
     float* stats_out = a.stats;
     if (splits > 1) {
         void* ws;
