@@ -274,6 +274,24 @@ int ssdseg_encode_targets(ssdseg_ctx* ctx, const float* anchors_corners, int a, 
                           const int32_t* gt_count, int b, int gmax, int c, float iou_threshold, const float* stds4_host,
                           float* labels, float* boxes, int32_t* match);
 
+/* ---------------------------------------------------------------- training metrics
+ * Per-image values of the three metric factories NB03#cell14 passes to compile(metrics=...); Keras averages them.
+ * jaccard_iou_segmentation_masks_metric (metrics.py:35-47): SOFT Jaccard, inter = sum t*p, total = sum(t+p) over pixels,
+ *   sum_c w_c * inter_c / (total_c - inter_c + 1e-7).  from_logits = 1: src = the low-resolution logits [n][h][w][4], p =
+ *   softmax(bilinear x(fy,fx)) recomputed per pixel (the training step never stores output-mask); from_logits = 0:
+ *   src = probabilities [n][h][w][4], fy = fx = 1.  y_true [n][h*fy][w*fx][4].  out [n]. */
+int ssdseg_metric_mask_iou(ssdseg_ctx* ctx, const float* src, int n, int h, int wdt, int c, int fy, int fx, int from_logits,
+                           const float* y_true, const float* class_weights_host, float* out);
+/* categorical_accuracy_metric (metrics.py:204-216): per class #anchors with one_hot(argmax p)[c] == y_true[c], / a,
+ *   weighted sum over classes.  y_true, y_pred [b][a][4]; out [b]. */
+int ssdseg_metric_label_accuracy(ssdseg_ctx* ctx, const float* y_true, const float* y_pred, int b, int a, int c,
+                                 const float* class_weights_host, float* out);
+/* jaccard_iou_bounding_boxes_metric (metrics.py:76-171): offsets decoded against the default boxes (anchors_centroids
+ *   [a][4] = cx, cy, w, h; device), IoU with the reference's conventions, averaged over the non-background anchors of
+ *   y_true (NaN for an image without objects, like the reference).  y_true, y_pred [b][a][4]; out [b]. */
+int ssdseg_metric_box_iou(ssdseg_ctx* ctx, const float* y_true, const float* y_pred, const float* anchors_centroids,
+                          const float* stds4_host, int b, int a, float* out);
+
 /* ---------------------------------------------------------------- K17..K19: inference tail
  * DecodeBoxesCentroidsOffsets.call (layers.py:58-79): offsets [b][a][4] -> corners (ymin,xmin,ymax,xmax) */
 int ssdseg_decode_boxes(ssdseg_ctx* ctx, const float* offsets, const float* anchors_centroids, int b, int a,

@@ -227,6 +227,10 @@ struct MarchLaunch {
 // than L2 holds: PMC FETCH_SIZE showed the full 6/4 halo for one-strip blocks, 1.05x for the eight-strip blocks of c = 32).
 // So: channel chunks of 64 (one wave = one strip's 256-byte pixel segment, line-aligned because c % 64 == 0), as many
 // strips as fit in MARCH_MAX_THREADS, the count chosen to waste the fewest strip slots in the last group of a row.
+inline long long march_min_waves() {   // row chunking stops once the launch has this many waves (A/B: SSDSEG_MARCH_WAVES)
+    static const long long v = getenv("SSDSEG_MARCH_WAVES") ? atoll(getenv("SSDSEG_MARCH_WAVES")) : 4096;
+    return v;
+}
 inline void march_split(int c, int wstrips, int* cb_out, int* spb_out, int* cchunks_out) {
     static const int env_cb = getenv("SSDSEG_MARCH_CB") ? atoi(getenv("SSDSEG_MARCH_CB")) : 0;        // A/B switches
     static const int env_mt = getenv("SSDSEG_MARCH_MAXT") ? atoi(getenv("SSDSEG_MARCH_MAXT")) : 0;
@@ -261,7 +265,7 @@ inline MarchLaunch march_geometry(int n, int h, int w, int c, MarchGeom* g, int 
     const int threads = ((g->cb * g->spb + 63) / 64) * 64;
     const long long waves_per_chunkrow = (long long)n * g->sgroups * cchunks * (threads / 64);
     int rows = h;
-    while (rows > 8 && waves_per_chunkrow * cdiv(h, rows) < 4096) rows = (rows + 1) / 2;
+    while (rows > 8 && waves_per_chunkrow * cdiv(h, rows) < march_min_waves()) rows = (rows + 1) / 2;
     g->rows = rows;
     g->chunks = cdiv(h, rows);
     g->sblocks = n * g->chunks * g->sgroups;

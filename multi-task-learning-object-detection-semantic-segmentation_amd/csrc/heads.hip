@@ -320,6 +320,123 @@ __global__ void softmax_rows4_kernel(const float* __restrict__ x, const float* _
         st4(out + i * 4, softmax4(view_apply4(ld4(x + i * 4), s, t, aff, act)));
 }
 
+
+// ------------------------------------------------------------------------------------------------ training metrics
+// (reference metrics.py; per-image values, Keras averages them).  All float reductions are two-level in fixed order.
+
+// soft Jaccard of the segmentation masks (metrics.py:35-47): per image and class  inter = sum t*p,  total = sum (t + p)
+// over the full-resolution pixels; p = softmax(upsampled logits) when FROM_LOGITS (the training path never stores the
+// probabilities) or the given probabilities.  grid (nblk, n) -> partial[n][nblk][8]
+template <bool FROM_LOGITS>
+__global__ void __launch_bounds__(256) mask_iou_partial_kernel(const float* __restrict__ src, int h, int w, int fy, int fx,
+                                                               const float* __restrict__ y_true, float* __restrict__ partial) {
+    __shared__ float red[256];
+    const int ho = h * fy, wo = w * fx;
+    const long long npix = (long long)ho * wo;
+    const int img = blockIdx.y;
+    const float ify = 1.f / (float)fy, ifx = 1.f / (float)fx;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long long)gridDim.x * 256) {
+        const int oy = (int)(i / wo), ox = (int)(i - (long long)oy * wo);
+        float4 pr;
+        if (FROM_LOGITS) pr = softmax4(up_logits(src, img, h, w, oy, ox, ify, ifx));
+        else pr = ld4(src + ((long long)img * npix + i) * 4);
+        const float4 t = ld4(y_true + ((long long)img * npix + i) * 4);
+        acc[0] = fmaf(t.x, pr.x, acc[0]); acc[1] = fmaf(t.y, pr.y, acc[1]); acc[2] = fmaf(t.z, pr.z, acc[2]); acc[3] = fmaf(t.w, pr.w, acc[3]);
+        acc[4] += t.x + pr.x; acc[5] += t.y + pr.y; acc[6] += t.z + pr.z; acc[7] += t.w + pr.w;
+    }
+    for (int k = 0; k < 8; ++k) {
+        __syncthreads();
+        red[threadIdx.x] = acc[k];
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) partial[((long long)img * gridDim.x + blockIdx.x) * 8 + k] = red[0];
+    }
+}
+__global__ void mask_iou_finish_kernel(const float* __restrict__ partial, int nblk, int n, float4 cw, float* __restrict__ out) {
+    const int img = blockIdx.x * blockDim.x + threadIdx.x;
+    if (img >= n) return;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < nblk; ++q)
+        for (int k = 0; k < 8; ++k) s[k] += partial[((long long)img * nblk + q) * 8 + k];
+    const float w[4] = {cw.x, cw.y, cw.z, cw.w};
+    float m = 0.f;
+    for (int c = 0; c < 4; ++c) m += s[c] / (s[4 + c] - s[c] + KEPS) * w[c];   // metrics.py:41-45
+    out[img] = m;
+}
+
+// weighted "categorical accuracy" of the anchor labels (metrics.py:204-216): per class the number of anchors where
+// one_hot(argmax p)[c] == y_true[c] (agreeing zeros count too), / #anchors, weighted sum.  One block per image, integer counts.
+__global__ void __launch_bounds__(256) label_accuracy_kernel(const float* __restrict__ y_true, const float* __restrict__ y_pred, int a,
+                                                             float4 cw, float* __restrict__ out) {
+    __shared__ int red[4][256];
+    const int img = blockIdx.x;
+    int cnt[4] = {0, 0, 0, 0};
+    for (int i = threadIdx.x; i < a; i += 256) {
+        const float4 t = ld4(y_true + ((long long)img * a + i) * 4), p = ld4(y_pred + ((long long)img * a + i) * 4);
+        int am = 0;   // first maximum, as tf.math.argmax
+        float best = p.x;
+        if (p.y > best) { best = p.y; am = 1; }
+        if (p.z > best) { best = p.z; am = 2; }
+        if (p.w > best) { best = p.w; am = 3; }
+        cnt[0] += ((am == 0) ? 1.f : 0.f) == t.x;
+        cnt[1] += ((am == 1) ? 1.f : 0.f) == t.y;
+        cnt[2] += ((am == 2) ? 1.f : 0.f) == t.z;
+        cnt[3] += ((am == 3) ? 1.f : 0.f) == t.w;
+    }
+    for (int k = 0; k < 4; ++k) red[k][threadIdx.x] = cnt[k];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float n = (float)a;
+        out[img] = (((float)red[0][0] / n * cw.x + (float)red[1][0] / n * cw.y) + (float)red[2][0] / n * cw.z) + (float)red[3][0] / n * cw.w;
+    }
+}
+
+// mean IoU of decoded predicted vs ground-truth boxes over the non-background anchors (metrics.py:76-171, including its
+// conventions: widths clamped at 0, corners c -+ (w-1)/2, areas w*h, +1 in the intersection extents, epsilon in the
+// denominator, 0/0 = NaN for an image without objects).  anchors: [a][4] = (cx, cy, w, h).  One block per image.
+__global__ void __launch_bounds__(256) box_iou_kernel(const float* __restrict__ y_true, const float* __restrict__ y_pred,
+                                                      const float* __restrict__ anchors, float4 sd, int a, float* __restrict__ out) {
+    __shared__ float red[2][256];
+    const int img = blockIdx.x;
+    float s_iou = 0.f, s_nb = 0.f;
+    for (int i = threadIdx.x; i < a; i += 256) {
+        const float4 t = ld4(y_true + ((long long)img * a + i) * 4), p = ld4(y_pred + ((long long)img * a + i) * 4);
+        const float4 an = ld4(anchors + (long long)i * 4);
+        const float nb = (fabsf(t.x) + fabsf(t.y) + fabsf(t.z) + fabsf(t.w)) > 0.f ? 1.f : 0.f;
+        float c[2][6];   // xmin, ymin, xmax, ymax, width, height of (pred, true)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float4 o = q == 0 ? p : t;
+            const float cx = (o.x * sd.x * an.z + an.x) * nb, cy = (o.y * sd.y * an.w + an.y) * nb;
+            const float wd = fmaxf(0.f, (expf(o.z * sd.z) - 1.f) * an.z) * nb, hg = fmaxf(0.f, (expf(o.w * sd.w) - 1.f) * an.w) * nb;
+            c[q][0] = (cx - (wd - 1.f) / 2.f) * nb; c[q][1] = (cy - (hg - 1.f) / 2.f) * nb;
+            c[q][2] = (cx + (wd - 1.f) / 2.f) * nb; c[q][3] = (cy + (hg - 1.f) / 2.f) * nb;
+            c[q][4] = wd; c[q][5] = hg;
+        }
+        const float wi = fmaxf(0.f, fminf(c[1][2], c[0][2]) - fmaxf(c[1][0], c[0][0]) + 1.f) * nb;
+        const float hi = fmaxf(0.f, fminf(c[1][3], c[0][3]) - fmaxf(c[1][1], c[0][1]) + 1.f) * nb;
+        const float inter = wi * hi;
+        s_iou += inter / (c[0][4] * c[0][5] + c[1][4] * c[1][5] - inter + KEPS);
+        s_nb += nb;
+    }
+    red[0][threadIdx.x] = s_iou; red[1][threadIdx.x] = s_nb;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) { red[0][threadIdx.x] += red[0][threadIdx.x + off]; red[1][threadIdx.x] += red[1][threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[img] = red[0][0] / red[1][0];
+}
+
 }  // namespace
 
 extern "C" {
@@ -460,6 +577,66 @@ int ssdseg_softmax_rows(ssdseg_ctx* ctx, const ssdseg_view* in, float* out, int 
     SSDSEG_ARG(c == 4, 5);
     SSDSEG_LAUNCH(ctx, 32.0 * rows, 0.0, softmax_rows4_kernel, dim3(ew_blocks(rows)), dim3(256), 0, in->x, in->scale, in->shift, in->act, out,
                   (long long)rows);
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+
+int ssdseg_metric_mask_iou(ssdseg_ctx* ctx, const float* src, int n, int h, int wdt, int c, int fy, int fx, int from_logits,
+                           const float* y_true, const float* class_weights_host, float* out) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(src != nullptr, 2);
+    SSDSEG_ARG(n > 0 && h > 0 && wdt > 0, 3);
+    SSDSEG_ARG(c == 4, 6);
+    SSDSEG_ARG(fy >= 1 && fx >= 1 && (from_logits || (fy == 1 && fx == 1)), 7);
+    SSDSEG_ARG(y_true != nullptr, 10);
+    SSDSEG_ARG(class_weights_host != nullptr, 11);
+    SSDSEG_ARG(out != nullptr, 12);
+    const long long npix = (long long)h * fy * wdt * fx;
+    int nblk = (int)((npix + 256 * 8 - 1) / (256 * 8));
+    if (nblk > 64) nblk = 64;
+    if (nblk < 1) nblk = 1;
+    void* ws;
+    int rc = ssdseg_workspace(ctx, (size_t)n * nblk * 8 * sizeof(float), &ws);
+    if (rc) return rc;
+    const double bytes = 16.0 * n * npix * (from_logits ? 1.0 : 2.0);
+    if (from_logits)
+        SSDSEG_LAUNCH(ctx, bytes, 0.0, mask_iou_partial_kernel<true>, dim3(nblk, n), dim3(256), 0, src, h, wdt, fy, fx, y_true, (float*)ws);
+    else
+        SSDSEG_LAUNCH(ctx, bytes, 0.0, mask_iou_partial_kernel<false>, dim3(nblk, n), dim3(256), 0, src, h, wdt, fy, fx, y_true, (float*)ws);
+    SSDSEG_LAUNCH_CHECK();
+    SSDSEG_LAUNCH(ctx, 0.0, 0.0, mask_iou_finish_kernel, dim3(cdiv(n, 64)), dim3(64), 0, (const float*)ws, nblk, n,
+                  make_float4(class_weights_host[0], class_weights_host[1], class_weights_host[2], class_weights_host[3]), out);
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+int ssdseg_metric_label_accuracy(ssdseg_ctx* ctx, const float* y_true, const float* y_pred, int b, int a, int c,
+                                 const float* class_weights_host, float* out) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(y_true != nullptr, 2);
+    SSDSEG_ARG(y_pred != nullptr, 3);
+    SSDSEG_ARG(b > 0 && a > 0, 4);
+    SSDSEG_ARG(c == 4, 6);
+    SSDSEG_ARG(class_weights_host != nullptr, 7);
+    SSDSEG_ARG(out != nullptr, 8);
+    SSDSEG_LAUNCH(ctx, 32.0 * b * a, 0.0, label_accuracy_kernel, dim3(b), dim3(256), 0, y_true, y_pred, a,
+                  make_float4(class_weights_host[0], class_weights_host[1], class_weights_host[2], class_weights_host[3]), out);
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+int ssdseg_metric_box_iou(ssdseg_ctx* ctx, const float* y_true, const float* y_pred, const float* anchors_centroids, const float* stds4_host,
+                          int b, int a, float* out) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(y_true != nullptr, 2);
+    SSDSEG_ARG(y_pred != nullptr, 3);
+    SSDSEG_ARG(anchors_centroids != nullptr, 4);
+    SSDSEG_ARG(stds4_host != nullptr, 5);
+    SSDSEG_ARG(b > 0 && a > 0, 6);
+    SSDSEG_ARG(out != nullptr, 8);
+    SSDSEG_LAUNCH(ctx, 32.0 * b * a, 0.0, box_iou_kernel, dim3(b), dim3(256), 0, y_true, y_pred, anchors_centroids,
+                  make_float4(stds4_host[0], stds4_host[1], stds4_host[2], stds4_host[3]), a, out);
     SSDSEG_LAUNCH_CHECK();
     return 0;
 }

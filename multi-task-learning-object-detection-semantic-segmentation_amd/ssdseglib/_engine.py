@@ -1064,6 +1064,42 @@ class Engine:
             else:
                 raise NotImplementedError(f"loss for output {name}: only the ssdseglib.losses functions are supported")
 
+    def configure_metrics(self, metrics: dict):
+        """bind compile(metrics={output: fn | [fn, ...]}) (NB03#cell14) to the device buffers of this engine's step: the
+        ssdseglib.metrics callables are evaluated by `ssdseg_metric_*` right after the forward pass, from the same target
+        buffers the losses use (needs configure_losses first); Keras naming `<output>_<function name>`"""
+        self._metrics = []
+        targets = {name: (op, kind) for name, op, kind in self._loss_names}
+        for t in self.model.outputs:
+            name = t.layer.name
+            fns = metrics.get(name)
+            if fns is None:
+                continue
+            for fn in (fns if isinstance(fns, (list, tuple)) else [fns]):
+                kind = getattr(fn, "metric_kind", None)
+                if kind is None:
+                    raise NotImplementedError(f"metric for output {name}: only the ssdseglib.metrics factories are supported")
+                if name not in targets:
+                    raise NotImplementedError(f"metric for output {name} needs a compiled loss on the same output (it shares its target buffer)")
+                op, lkind = targets[name]
+                want = {"mask_iou": "mask", "label_accuracy": "conf", "box_iou": "loc"}[kind]
+                if want != lkind:
+                    raise ValueError(f"metric {fn.__name__} does not fit output {name}")
+                self._metrics.append((f"{name}_{fn.__name__}", kind, fn, op, self.ctx.empty(self.batch)))
+
+    def compute_metrics(self):
+        """launch the metric kernels on the outputs of the forward pass just run (asynchronous; read by `losses()`)"""
+        for key, kind, fn, op, out in getattr(self, "_metrics", []):
+            if kind == "mask_iou":
+                s = op.logits.store
+                self.ctx.call("ssdseg_metric_mask_iou", s.buf, s.n, s.h, s.w, s.c, op.fy, op.fx, 1, op.y_true, fn._cw, out)
+            elif kind == "label_accuracy":
+                p = op.probs
+                self.ctx.call("ssdseg_metric_label_accuracy", op.y_labels, p.buf, p.n, p.h * p.w, p.c, fn._cw, out)
+            else:
+                p = op.boxes
+                self.ctx.call("ssdseg_metric_box_iou", op.y_boxes, p.buf, fn.anchors_on(self.ctx), fn._stds, p.n, p.h * p.w, out)
+
     def set_targets(self, targets: dict):
         for name, op, kind in self._loss_names:
             y = targets[name]
@@ -1084,6 +1120,8 @@ class Engine:
             out[f"{name}_loss"] = v
             total += w * v
         out["loss"] = total
+        for key, kind, fn, op, buf in getattr(self, "_metrics", []):
+            out[key] = float(buf.download().mean())        # batch mean, NaN-propagating like Keras (quirk Q10)
         return out
 
     def train_step(self, images=None, targets=None, optimizer=None, allreduce=None, world=1):
@@ -1092,6 +1130,7 @@ class Engine:
         if targets is not None:
             self.set_targets(targets)
         self.forward()
+        self.compute_metrics()
         self.backward()
         if allreduce is not None:
             allreduce()
@@ -1131,6 +1170,7 @@ def engine_for(model: K.Model, batch_size: int, training: bool) -> Engine:
             if comp is None:
                 raise RuntimeError("call model.compile(optimizer=..., loss=...) before fit / train_on_batch")
             eng.configure_losses(comp["loss"], comp["loss_weights"])
+            eng.configure_metrics(comp.get("metrics") or {})
         cache[key] = eng
     return cache[key]
 
@@ -1142,6 +1182,7 @@ def eval_engine_for(model: K.Model, batch_size: int) -> Engine:
     if key not in cache:
         eng = Engine(model, batch_size, False)
         eng.configure_losses(model._compiled["loss"], model._compiled["loss_weights"])
+        eng.configure_metrics(model._compiled.get("metrics") or {})
         cache[key] = eng
     return cache[key]
 
@@ -1224,6 +1265,7 @@ def run_fit(model: K.Model, data, epochs=1, validation_data=None, verbose=0) -> 
                 eng.set_input(x)
                 eng.set_targets(y)
                 eng.forward()
+                eng.compute_metrics()
                 for k, v in eng.losses().items():
                     vs[k] = vs.get(k, 0.0) + v * x.shape[0]
                 vseen += x.shape[0]

@@ -478,3 +478,48 @@ def adam_step(p, g, m, v, step, lr=1e-4, b1=0.9, b2=0.999, eps=1e-7):
     alpha = lr * np.sqrt(1 - b2 ** step) / (1 - b1 ** step)
     p = p - alpha * m / (np.sqrt(v) + eps)
     return p.astype(g.dtype), m.astype(g.dtype), v.astype(g.dtype)
+
+
+# --------------------------------------------------------------------------------------------- training metrics
+KEPS = 1e-7   # tf.keras.backend.epsilon()
+
+
+def metric_mask_iou(y_true, y_pred, class_weights):
+    """metrics.jaccard_iou_segmentation_masks_metric (metrics.py:35-47): SOFT Jaccard on probabilities -> (batch,)."""
+    y_true, y_pred = np.asarray(y_true, np.float64), np.asarray(y_pred, np.float64)
+    inter = (y_true * y_pred).sum(axis=(1, 2))
+    total = (y_true + y_pred).sum(axis=(1, 2))
+    return (inter / (total - inter + KEPS) * np.asarray(class_weights, np.float64)[None]).sum(-1)
+
+
+def metric_label_accuracy(y_true, y_pred, class_weights):
+    """metrics.categorical_accuracy_metric (metrics.py:204-216): equal(one_hot(argmax p), y_true) counted per class over the
+    boxes (agreeing zeros count), / #boxes, weighted sum -> (batch,)."""
+    y_true, y_pred = np.asarray(y_true, np.float32), np.asarray(y_pred, np.float32)
+    onehot = np.eye(y_pred.shape[-1], dtype=np.float32)[y_pred.argmax(-1)]
+    tp = (onehot == y_true).astype(np.float64).sum(axis=1)
+    return (tp / y_true.shape[1] * np.asarray(class_weights, np.float64)[None]).sum(-1)
+
+
+def metric_box_iou(y_true, y_pred, cx, cy, w, h, stds):
+    """metrics.jaccard_iou_bounding_boxes_metric (metrics.py:76-171), every convention of the reference kept: not_background
+    from |y_true|, widths clamped at 0, corners c -+ (w-1)/2, areas w*h, +1 extents of the intersection, epsilon, and
+    sum / #non-background (NaN without objects) -> (batch,)."""
+    y_true, y_pred = np.asarray(y_true, np.float64), np.asarray(y_pred, np.float64)
+    cx, cy, w, h = (np.asarray(v, np.float64) for v in (cx, cy, w, h))
+    nb = (np.abs(y_true).sum(-1) > 0).astype(np.float64)
+
+    def dec(o):
+        x = (o[..., 0] * stds[0] * w + cx) * nb
+        y = (o[..., 1] * stds[1] * h + cy) * nb
+        ww = np.maximum(0.0, (np.exp(o[..., 2] * stds[2]) - 1.0) * w) * nb
+        hh = np.maximum(0.0, (np.exp(o[..., 3] * stds[3]) - 1.0) * h) * nb
+        return (x - (ww - 1) / 2) * nb, (y - (hh - 1) / 2) * nb, (x + (ww - 1) / 2) * nb, (y + (hh - 1) / 2) * nb, ww, hh
+
+    px0, py0, px1, py1, pw, ph = dec(y_pred)
+    tx0, ty0, tx1, ty1, tw, th = dec(y_true)
+    wi = np.maximum(0.0, np.minimum(tx1, px1) - np.maximum(tx0, px0) + 1.0) * nb
+    hi = np.maximum(0.0, np.minimum(ty1, py1) - np.maximum(ty0, py0) + 1.0) * nb
+    inter = wi * hi
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return (inter / (pw * ph + tw * th - inter + KEPS)).sum(-1) / nb.sum(-1)

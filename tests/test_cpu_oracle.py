@@ -213,3 +213,27 @@ def test_seg_suppress_is_batch_global():
     probs = np.ones((2, 5, 4), np.float32)
     out = O.seg_suppress(mask, probs)
     assert out[0, 0].tolist() == [1, 0, 0, 1]         # ... and is enabled for image 0 too (quirk Q6)
+
+
+def test_metrics_hand_worked():
+    """the three training metrics of reference metrics.py on cases small enough to do by hand"""
+    w = (0.1, 0.2, 0.3, 0.4)
+    # masks: 1x1x2 image; pixel 0 true class 1, predicted (0.5, 0.5, 0, 0); pixel 1 true class 0, predicted (1, 0, 0, 0)
+    yt = np.array([[[[0, 1, 0, 0], [1, 0, 0, 0]]]], np.float32)
+    yp = np.array([[[[0.5, 0.5, 0, 0], [1, 0, 0, 0]]]], np.float32)
+    # class 0: inter 1, total 1 + 1.5 -> 1/1.5; class 1: inter 0.5, total 1 + 0.5 -> 0.5/1.0; classes 2, 3: 0/(0+eps) = 0
+    assert np.allclose(O.metric_mask_iou(yt, yp, w), 0.1 * (1 / 1.5) + 0.2 * 0.5, atol=1e-6)
+    # labels: 3 boxes, truth classes (0, 2, 2), arg-max predictions (0, 2, 1)
+    lt = np.eye(4, dtype=np.float32)[[0, 2, 2]][None]
+    lp = np.array([[[0.7, 0.1, 0.1, 0.1], [0.1, 0.2, 0.6, 0.1], [0.1, 0.5, 0.3, 0.1]]], np.float32)
+    # per class agreeing entries over the 3 boxes: class 0: 3, class 1: 2 (box 2 predicted 1, truth 0 there), class 2: 2, class 3: 3
+    assert np.allclose(O.metric_label_accuracy(lt, lp, w), (0.1 * 3 + 0.2 * 2 + 0.3 * 2 + 0.4 * 3) / 3)
+    # boxes: one default box (cx, cy, w, h) = (50, 40, 20, 10), stds 1; truth offsets (0, 0, ln 2, ln 2) -> 20 x 10 box;
+    # prediction identical -> IoU = (19+1)(9+1) / (200 + 200 - 200) = 1; a second, background anchor contributes nothing
+    cx, cy, aw, ah = (np.array(v, np.float32) for v in ([50, 7], [40, 7], [20, 5], [10, 5]))
+    t = np.array([[[0, 0, np.log(2.0), np.log(2.0)], [0, 0, 0, 0]]], np.float32)
+    assert np.allclose(O.metric_box_iou(t, t, cx, cy, aw, ah, (1, 1, 1, 1)), 1.0, atol=1e-6)
+    p = t.copy(); p[0, 0, 0] = 0.5                      # prediction shifted right by half a box width (10 px)
+    # intersection extent x: min(59.5, 69.5) - max(40.5, 50.5) + 1 = 10, y: 10 -> 100 / (200 + 200 - 100)
+    assert np.allclose(O.metric_box_iou(t, p, cx, cy, aw, ah, (1, 1, 1, 1)), 100 / 300, atol=1e-6)
+    assert np.isnan(O.metric_box_iou(np.zeros_like(t), p, cx, cy, aw, ah, (1, 1, 1, 1))[0])   # no objects: 0/0 like the reference
