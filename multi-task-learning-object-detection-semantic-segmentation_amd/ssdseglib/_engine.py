@@ -748,6 +748,11 @@ class Engine:
             mid = Store(self, n, h, w, s.c, layer.name + ":dw")
             self.stores.append(mid)
             dw = self._emit(DwOp(self, layer, "depthwise_kernel", inp, mid, layer.strides[0], layer.dilation_rate[0]))
+            src = layer.inbound[0]
+            # sole consumer of a BatchNorm(+ReLU) output (the decoder's sepconv behind the 3x3 conv): that BN's backward sums
+            # ride in the depthwise backward, as for the MBConv blocks
+            dw.fuse_input_bn = (inp is ins[0] and ins[0].bn is not None and ins[0].store.parent is None
+                                and len(self.cons.get(id(src), [])) == 1 and id(src) not in {id(t) for t in self.model.outputs})
             mid.stats = None   # no BatchNormalization between the two halves
             dw.out_val = Val(mid)
             st = self._out_store(layer, out_t.shape)
