@@ -15,6 +15,7 @@ struct ssdseg_ctx {
     bool owns_stream;
     void* workspace;
     size_t workspace_bytes;
+    size_t ws_reserved;   // front part of the workspace held by a composite entry point while it calls others (runtime.hip)
     int num_cus;
     bool capturing;
     ssdseg_timing* timing;  // non-null while kernel timing is enabled

@@ -20,8 +20,16 @@ int ssdseg_hip_fail(hipError_t e, const char* what) {
     return -(int)e;
 }
 
+// A composite entry point (one that calls other entry points) keeps its own scratch at the front of the workspace and sets
+// ctx->ws_reserved to its size for the duration of the nested calls: they get the region BEHIND it.  The composite sizes the
+// buffer up front (growing here would free the region it is using), so a nested request that does not fit is an error.
 int ssdseg_workspace(ssdseg_ctx* ctx, size_t bytes, void** out) {
+    bytes += ctx->ws_reserved;
     if (bytes > ctx->workspace_bytes) {
+        if (ctx->ws_reserved != 0) {
+            ssdseg_set_error("nested workspace request of %zu bytes exceeds the composite call's reservation (%zu)", bytes, ctx->workspace_bytes);
+            return SSDSEG_EINVAL(0);
+        }
         if (ctx->capturing) {
             ssdseg_set_error("workspace of %zu bytes needed during graph capture (have %zu): call ssdseg_ctx_reserve first",
                              bytes, ctx->workspace_bytes);
@@ -36,7 +44,7 @@ int ssdseg_workspace(ssdseg_ctx* ctx, size_t bytes, void** out) {
         SSDSEG_HIP(hipMalloc(&ctx->workspace, want));
         ctx->workspace_bytes = want;
     }
-    *out = ctx->workspace;
+    *out = (char*)ctx->workspace + ctx->ws_reserved;
     return 0;
 }
 

@@ -17,7 +17,8 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 # because the product's default dispatch picks a family per shape by measured speed and would leave the others untested.
 KERNEL_FAMILIES = {
     "default": {},
-    "general": {"SSDSEG_NO_WRES": "1", "SSDSEG_DW_FWD": "lds", "SSDSEG_DW_BWD": "lds", "SSDSEG_CONV3_WGRAD": "taps"},
+    "general": {"SSDSEG_NO_WRES": "1", "SSDSEG_DW_FWD": "lds", "SSDSEG_DW_BWD": "lds", "SSDSEG_CONV3_WGRAD": "taps",
+                "SSDSEG_CONV3_NARROW": "0"},
     "general-reg": {"SSDSEG_NO_WRES": "1", "SSDSEG_DW_FWD": "lds", "SSDSEG_DW_BWD": "reg"},
     "resident-fused": {"SSDSEG_WRES_FORCE": "1", "SSDSEG_PW_FUSED": "1"},
     "split-k": {"SSDSEG_NO_WRES": "1", "SSDSEG_SPLITK": "1"},
@@ -50,7 +51,7 @@ def rng():
 
 @pytest.fixture(params=list(KERNEL_FAMILIES))
 def kernel_family(request, monkeypatch):
-    for k in ("SSDSEG_NO_WRES", "SSDSEG_WRES_FORCE", "SSDSEG_PW_FUSED", "SSDSEG_DW_FWD", "SSDSEG_DW_BWD", "SSDSEG_SPLITK", "SSDSEG_CONV3_WGRAD"):
+    for k in ("SSDSEG_NO_WRES", "SSDSEG_WRES_FORCE", "SSDSEG_PW_FUSED", "SSDSEG_DW_FWD", "SSDSEG_DW_BWD", "SSDSEG_SPLITK", "SSDSEG_CONV3_WGRAD", "SSDSEG_CONV3_NARROW"):
         monkeypatch.delenv(k, raising=False)
     for k, v in KERNEL_FAMILIES[request.param].items():
         monkeypatch.setenv(k, v)

@@ -40,8 +40,12 @@ def gview_inputs(rng, shape, act):
 
 @pytest.mark.parametrize("n,h,w,cin,cout", [(2, 9, 11, 16, 32), (1, 12, 16, 304, 256), (2, 8, 8, 256, 4), (1, 5, 5, 24, 8), (1, 1, 1, 8, 8),
                                             (3, 14, 40, 72, 96)])   # 40 = one full + one partial 32-pixel step per image row
-def test_conv3x3_fwd_bwd(ctx, rng, monkeypatch, n, h, w, cin, cout):
+@pytest.mark.parametrize("narrow", ["1", "0"])    # cout <= 8: tap-expanded pointwise GEMMs ("1", default) vs the implicit-GEMM kernels
+def test_conv3x3_fwd_bwd(ctx, rng, monkeypatch, n, h, w, cin, cout, narrow):
     from ssdseglib import _hip as H
+    if narrow == "0" and cout > 8:
+        pytest.skip("only one kernel family for wide outputs")
+    monkeypatch.setenv("SSDSEG_CONV3_NARROW", narrow)
     act = O.ACT_RELU6
     x, sc, sh, a = view_inputs(rng, (n, h, w, cin), act)
     wgt = (rng.normal(0, 1, (3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
