@@ -142,6 +142,8 @@ PW_CASES = [
     (1500, 960, 160),    # forward the same way (BN statistics come from the split-K reduce kernel)
     (70001, 24, 144),    # fused dx+dW kernel: more row tiles than blocks, ragged last tile, 4.5 column chunks
     (66000, 32, 192),    # fused, 6 chunks (largest shape the fused kernel takes)
+    (300, 200, 64),      # deep steps (two 32-deep sub-tiles per barrier pair): reduction of 6.25 sub-tiles, both directions
+    (9600, 960, 160),    # the 15x20-stage project conv as it runs in the bench
 ]
 
 
