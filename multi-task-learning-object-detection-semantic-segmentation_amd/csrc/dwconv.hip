@@ -404,17 +404,17 @@ int dw_bwd_impl(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, const ss
         float* part = (float*)ws;
         float* bnpart = part + (size_t)nparts * 9 * c;
         const bool wfull = wdt % MTW == 0 && dilation == 1;
-#define DW_BWD_MARCH(BN_, WF_, AC_, ...)                                                                                                         \
-    SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_bwd_march_kernel<BN_, WF_, AC_, ##__VA_ARGS__>), ml.grid, ml.block, ml.lds, mg, v, w, gv, dx, part, accumulate, \
+#define DW_BWD_MARCH(BN_, WF_, AC_, DIL_)                                                                                                        \
+    SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_bwd_march_kernel<BN_, WF_, AC_, DIL_>), ml.grid, ml.block, ml.lds, mg, v, w, gv, dx, part, accumulate, \
                   fuse ? bn->mean : (const float*)nullptr, fuse ? bn->invstd : (const float*)nullptr, fuse ? bnpart : (float*)nullptr)
         if (dilation > 1 && accumulate) DW_BWD_MARCH(false, false, true, true);
         else if (dilation > 1) DW_BWD_MARCH(false, false, false, true);
-        else if (fuse && wfull) DW_BWD_MARCH(true, true, false);        // (the fused BN sums imply a sole consumer: never accumulating)
-        else if (fuse) DW_BWD_MARCH(true, false, false);
-        else if (wfull && accumulate) DW_BWD_MARCH(false, true, true);
-        else if (wfull) DW_BWD_MARCH(false, true, false);
-        else if (accumulate) DW_BWD_MARCH(false, false, true);
-        else DW_BWD_MARCH(false, false, false);
+        else if (fuse && wfull) DW_BWD_MARCH(true, true, false, false);        // (the fused BN sums imply a sole consumer: never accumulating)
+        else if (fuse) DW_BWD_MARCH(true, false, false, false);
+        else if (wfull && accumulate) DW_BWD_MARCH(false, true, true, false);
+        else if (wfull) DW_BWD_MARCH(false, true, false, false);
+        else if (accumulate) DW_BWD_MARCH(false, false, true, false);
+        else DW_BWD_MARCH(false, false, false, false);
 #undef DW_BWD_MARCH
         SSDSEG_LAUNCH_CHECK();
         rc = ssdseg_colsum(ctx, part, nparts, 9LL * c, dw);

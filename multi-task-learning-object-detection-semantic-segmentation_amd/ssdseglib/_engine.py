@@ -732,6 +732,9 @@ class Engine:
             self._lower_conv(layer, ins[0], setv)
         elif isinstance(layer, K.DepthwiseConv2D):
             assert layer.strides[0] == layer.strides[1] and layer.dilation_rate[0] == layer.dilation_rate[1]
+            if out_t.shape[-1] % 4 != 0:
+                raise NotImplementedError(f"{layer.name}: {out_t.shape[-1]} channels -- the HIP kernels work on 16-byte channel vectors (multiples of "
+                                          "4 channels); ShuffleNetV2 model_size '1x' / '2x' split into 58 / 122 channels, use '0.5x' or '1.5x'")
             st = self._out_store(layer, out_t.shape)
             op = self._emit(DwOp(self, layer, "depthwise_kernel", self._dense(ins[0], layer.name), st, layer.strides[0], layer.dilation_rate[0]))
             src = layer.inbound[0]
