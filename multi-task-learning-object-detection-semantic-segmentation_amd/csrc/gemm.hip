@@ -1593,7 +1593,10 @@ int ssdseg_conv3x3_bwd_weight(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, c
         const double m = (double)n * h * wdt;
         const double cost_bytes = 4.0 * (m * cin + (dy->scale != nullptr ? 2.0 : 1.0) * m * cout + 9.0 * cin * cout);
         const double cost_flops = 18.0 * m * cin * cout;
-        if (wn == 4) SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (conv3_wgrad9_kernel<4>), grid, dim3(C9_THREADS), lds, a);
+        const char* w12 = getenv("SSDSEG_CONV3_WGRAD");   // "nine": the nine-wave kernel for the 128-column tiles as well
+        if (wn == 4 && !(w12 != nullptr && !strcmp(w12, "nine")))
+            SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, conv3_wgrad12_kernel, grid, dim3(C12_THREADS), lds, a);
+        else if (wn == 4) SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (conv3_wgrad9_kernel<4>), grid, dim3(C9_THREADS), lds, a);
         else SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (conv3_wgrad9_kernel<1>), grid, dim3(C9_THREADS), lds, a);
         SSDSEG_LAUNCH_CHECK();
         if (splits == 1) {

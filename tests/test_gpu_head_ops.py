@@ -70,7 +70,11 @@ def test_conv3x3_fwd_bwd(ctx, rng, monkeypatch, n, h, w, cin, cout, narrow):
     assert rel_err(ddx.download(), dx_ref + base) < 2e-5
     ddw = ctx.empty(wgt.shape)
     ctx.call("ssdseg_conv3x3_bwd_weight", H.view(dx_, dsc, dsh, act), cin, H.gview(*bufs, act=O.ACT_RELU6), ddw, n, h, w, cin, cout)
-    assert rel_err(ddw.download(), dw_ref) < 5e-5      # default: all nine taps in one pass (conv3_wgrad.h)
+    assert rel_err(ddw.download(), dw_ref) < 5e-5      # default: all nine taps in one pass (conv3_wgrad.h; twelve waves for cout > 32)
+    monkeypatch.setenv("SSDSEG_CONV3_WGRAD", "nine")   # one wave per tap for every width
+    ddw.upload(np.zeros(wgt.shape, np.float32))
+    ctx.call("ssdseg_conv3x3_bwd_weight", H.view(dx_, dsc, dsh, act), cin, H.gview(*bufs, act=O.ACT_RELU6), ddw, n, h, w, cin, cout)
+    assert rel_err(ddw.download(), dw_ref) < 5e-5
     monkeypatch.setenv("SSDSEG_CONV3_WGRAD", "taps")   # the nine shifted weight-gradient GEMMs
     ddw.upload(np.zeros(wgt.shape, np.float32))
     ctx.call("ssdseg_conv3x3_bwd_weight", H.view(dx_, dsc, dsh, act), cin, H.gview(*bufs, act=O.ACT_RELU6), ddw, n, h, w, cin, cout)
