@@ -509,8 +509,10 @@ struct WGradArgs {
 constexpr int rw_of(int wr) { return wr == 4 ? 16 : 32; }
 
 // WI waves along the output rows (k), WR waves splitting the reduction rows (m); WI*WR == 4.
+// occupancy targets where the raw-load staging would otherwise cost a wave per SIMD (184 registers for <4,1,3>: 2 waves instead of 3)
+constexpr int wgrad_min_waves(int WI, int WR, int WN) { return (WI == 4 && WN == 3) ? 3 : ((WI == 4 && WN <= 2) ? 3 : 1); }
 template <int WI, int WR, int WN>
-__global__ void __launch_bounds__(256) gemm_wgrad_kernel(WGradArgs p) {
+__global__ void __launch_bounds__(256, wgrad_min_waves(WI, WR, WN)) gemm_wgrad_kernel(WGradArgs p) {
     constexpr int RW = rw_of(WR);
     constexpr int BI = 32 * WI, BJ = 32 * WN, BRT = RW * WR;
     extern __shared__ float smem[];
@@ -533,11 +535,31 @@ __global__ void __launch_bounds__(256) gemm_wgrad_kernel(WGradArgs p) {
     constexpr int XV = BRT * BI / 4;   // float4 per X tile (== 256 * 2)
     constexpr int YV = BRT * BJ / 4;
     constexpr int XQ = (XV + 255) / 256, YQ = (YV + 255) / 256;
-    float4 xreg[XQ], yreg[YQ];
+    // Staging in two halves (as in gemm_wres.h): load_tiles() only issues the RAW loads of the next step; store_tiles() -- one
+    // MFMA phase and a barrier later -- applies the views and writes LDS.  With the view arithmetic inside load_tiles every
+    // step waited for its global loads before the first MFMA.  The per-channel view coefficients sit in LDS (loaded once).
+    float4 xraw[XQ], graw[YQ], yraw[YQ];
+    unsigned xok = 0, yok = 0;   // bit q (stem: bit 4q + element): the slot holds real data
+    float* Xc = smem + BRT * (BI + BJ);   // [2][BI]: scale, shift of the X view
+    float* Yc = Xc + 2 * BI;              // [4][BJ]: scale, shift, k1, k0 of the gradient view
+    for (int i = t; i < BI; i += 256) {
+        const int k = i0 + i;
+        const bool ok = xaff && k < p.K;
+        Xc[i] = ok ? p.xs[k] : 1.f;
+        Xc[BI + i] = ok ? p.xt[k] : 0.f;
+    }
+    for (int i = t; i < BJ; i += 256) {
+        const int n = j0 + i;
+        const bool ok = gaff && n < p.N;
+        Yc[i] = ok ? p.gs[n] : 1.f;
+        Yc[BJ + i] = ok ? p.gt[n] : 0.f;
+        Yc[2 * BJ + i] = ok ? p.gk1[n] : 0.f;
+        Yc[3 * BJ + i] = ok ? p.gk0[n] : 0.f;
+    }
+    // (made visible by the first barrier of the main loop)
 
-    // per-thread channel coefficients are fixed across steps when the tile width divides 256 float4 columns;
-    // otherwise they are re-read per step (they sit in L1).
     auto load_tiles = [&](long long mrow) {
+        xok = yok = 0;
 #pragma unroll
         for (int q = 0; q < XQ; ++q) {
             const int idx = t + 256 * q;
@@ -559,10 +581,10 @@ __global__ void __launch_bounds__(256) gemm_wgrad_kernel(WGradArgs p) {
                         const int rq = k + qq, tap = rq / 3, ci = rq - tap * 3, kh = tap / 3, kw = tap - kh * 3;
                         const int hi = 2 * ho + kh - p.stemPt, wi = 2 * wo + kw - p.stemPl;
                         const bool okq = m < mend && rq < p.K && hi >= 0 && hi < p.stemH && wi >= 0 && wi < p.stemW;
-                        const float xv = p.x[okq ? ((img * p.stemH + hi) * p.stemW + wi) * 3 + ci : 0];
-                        e[qq] = okq ? fmaf(xv, p.stemScale, p.stemOffset) : 0.f;
+                        e[qq] = p.x[okq ? ((img * p.stemH + hi) * p.stemW + wi) * 3 + ci : 0];
+                        xok |= (okq ? 1u : 0u) << (4 * q + qq);
                     }
-                    xreg[q] = make_float4(e[0], e[1], e[2], e[3]);
+                    xraw[q] = make_float4(e[0], e[1], e[2], e[3]);
                     continue;
                 }
                 if (p.convH > 0 && ok) {
@@ -573,47 +595,58 @@ __global__ void __launch_bounds__(256) gemm_wgrad_kernel(WGradArgs p) {
                     ok = hy >= 0 && hy < p.convH && wx >= 0 && wx < p.convW;
                     src = (img * p.convH + hy) * p.convW + wx;
                 }
-                {
-                    const int kk = ok ? k : 0;
-                    float4 s = f4(1.f), sh = f4(0.f);
-                    if (xaff) { s = ld4(p.xs + kk); sh = ld4(p.xt + kk); }
-                    v = view_affine4(ld4(p.x + (ok ? src * p.ldx + k : 0)), s, sh, xlo, xhi);
-                    if (!ok) v = f4(0.f);
-                }
+                v = ld4(p.x + (ok ? src * p.ldx + k : 0));
+                xok |= (ok ? 1u : 0u) << (p.stem ? 4 * q : q);
             }
-            xreg[q] = v;
+            xraw[q] = v;
         }
 #pragma unroll
         for (int q = 0; q < YQ; ++q) {
             const int idx = t + 256 * q;
-            float4 v = f4(0.f);
+            float4 g4 = f4(0.f), y4 = f4(0.f);
             if (idx < YV) {
                 const int rr = idx / (BJ / 4), c4 = idx % (BJ / 4);
                 const long long m = mrow + rr;
                 const int n = j0 + c4 * 4;
-                {
-                    const bool ok = m < mend && n < p.N;
-                    const long long o = ok ? m * p.ldy + n : 0;
-                    const int nn = ok ? n : 0;
-                    float4 gs = f4(1.f), gt = f4(0.f), gk1 = f4(0.f), gk0 = f4(0.f);
-                    if (gaff) { gs = ld4(p.gs + nn); gt = ld4(p.gt + nn); gk1 = ld4(p.gk1 + nn); gk0 = ld4(p.gk0 + nn); }
-                    v = gview_apply4(ld4(p.g + o), ld4(yptr + o), gs, gt, gk1, gk0, yact);
-                    if (!ok) v = f4(0.f);
-                }
+                const bool ok = m < mend && n < p.N;
+                const long long o = ok ? m * p.ldy + n : 0;
+                g4 = ld4(p.g + o);
+                y4 = ld4(yptr + o);
+                yok |= (ok ? 1u : 0u) << q;
             }
-            yreg[q] = v;
+            graw[q] = g4;
+            yraw[q] = y4;
         }
     };
     auto store_tiles = [&]() {
 #pragma unroll
         for (int q = 0; q < XQ; ++q) {
             const int idx = t + 256 * q;
-            if (idx < XV) st4(Xs + idx * 4, xreg[q]);
+            if (idx < XV) {
+                const int c4 = idx % (BI / 4);
+                float4 v;
+                if (p.stem) {
+                    v.x = ((xok >> (4 * q + 0)) & 1u) ? fmaf(xraw[q].x, p.stemScale, p.stemOffset) : 0.f;
+                    v.y = ((xok >> (4 * q + 1)) & 1u) ? fmaf(xraw[q].y, p.stemScale, p.stemOffset) : 0.f;
+                    v.z = ((xok >> (4 * q + 2)) & 1u) ? fmaf(xraw[q].z, p.stemScale, p.stemOffset) : 0.f;
+                    v.w = ((xok >> (4 * q + 3)) & 1u) ? fmaf(xraw[q].w, p.stemScale, p.stemOffset) : 0.f;
+                } else {
+                    v = view_affine4(xraw[q], ld4(Xc + c4 * 4), ld4(Xc + BI + c4 * 4), xlo, xhi);
+                    if (!((xok >> q) & 1u)) v = f4(0.f);
+                }
+                st4(Xs + idx * 4, v);
+            }
         }
 #pragma unroll
         for (int q = 0; q < YQ; ++q) {
             const int idx = t + 256 * q;
-            if (idx < YV) st4(Ys + idx * 4, yreg[q]);
+            if (idx < YV) {
+                const int c4 = idx % (BJ / 4);
+                float4 v = gview_apply4(graw[q], yraw[q], ld4(Yc + c4 * 4), ld4(Yc + BJ + c4 * 4), ld4(Yc + 2 * BJ + c4 * 4),
+                                        ld4(Yc + 3 * BJ + c4 * 4), yact);
+                if (!((yok >> q) & 1u)) v = f4(0.f);
+                st4(Ys + idx * 4, v);
+            }
         }
     };
 
@@ -925,7 +958,7 @@ int launch_rowA(ssdseg_ctx* ctx, const RowAArgs& a0) {
 
 template <int WI, int WR>
 int launch_wgrad_wn(ssdseg_ctx* ctx, const WGradArgs& a, int wn, dim3 grid) {
-    size_t lds = (size_t)(rw_of(WR) * WR) * (32 * WI + 32 * wn) * sizeof(float);
+    size_t lds = ((size_t)(rw_of(WR) * WR) * (32 * WI + 32 * wn) + 2 * 32 * WI + 4 * 32 * wn) * sizeof(float);   // tiles + view coefficients
     size_t red = (size_t)(WR - 1) * WI * wn * 16 * 64 * sizeof(float);
     if (red > lds) lds = red;
     const double share = 1.0 / ((double)grid.x * grid.y);   // every (k-tile, n-tile) block column re-reads its operands
