@@ -510,7 +510,7 @@ constexpr int rw_of(int wr) { return wr == 4 ? 16 : 32; }
 
 // WI waves along the output rows (k), WR waves splitting the reduction rows (m); WI*WR == 4.
 // occupancy targets where the raw-load staging would otherwise cost a wave per SIMD (184 registers for <4,1,3>: 2 waves instead of 3)
-constexpr int wgrad_min_waves(int WI, int WR, int WN) { return (WI == 4 && WN == 3) ? 3 : ((WI == 4 && WN <= 2) ? 3 : 1); }
+constexpr int wgrad_min_waves(int WI, int WR, int WN) { return (WI == 4 && WN <= 2) ? 3 : 1; }
 template <int WI, int WR, int WN>
 __global__ void __launch_bounds__(256, wgrad_min_waves(WI, WR, WN)) gemm_wgrad_kernel(WGradArgs p) {
     constexpr int RW = rw_of(WR);
@@ -538,7 +538,9 @@ __global__ void __launch_bounds__(256, wgrad_min_waves(WI, WR, WN)) gemm_wgrad_k
     // Staging in two halves (as in gemm_wres.h): load_tiles() only issues the RAW loads of the next step; store_tiles() -- one
     // MFMA phase and a barrier later -- applies the views and writes LDS.  With the view arithmetic inside load_tiles every
     // step waited for its global loads before the first MFMA.  The per-channel view coefficients sit in LDS (loaded once).
-    float4 xraw[XQ], graw[YQ], yraw[YQ];
+    // (RAW = false: the 96-column tiles of the 30x40 / 15x20 stages, where the extra staging registers cost a wave per SIMD)
+    constexpr bool RAW = !(WI == 4 && WN == 3);
+    float4 xraw[RAW ? XQ : 1], graw[RAW ? YQ : 1], yraw[RAW ? YQ : 1];
     unsigned xok = 0, yok = 0;   // bit q (stem: bit 4q + element): the slot holds real data
     float* Xc = smem + BRT * (BI + BJ);   // [2][BI]: scale, shift of the X view
     float* Yc = Xc + 2 * BI;              // [4][BJ]: scale, shift, k1, k0 of the gradient view
@@ -650,18 +652,104 @@ __global__ void __launch_bounds__(256, wgrad_min_waves(WI, WR, WN)) gemm_wgrad_k
         }
     };
 
+    // ---- the original staging (view arithmetic at load time), kept for the shapes where it measured faster
+    float4 xreg[RAW ? 1 : XQ], yreg[RAW ? 1 : YQ];   // !RAW: transformed at load time
+
+    // per-thread channel coefficients are fixed across steps when the tile width divides 256 float4 columns;
+    // otherwise they are re-read per step (they sit in L1).
+    auto load_tiles_t = [&](long long mrow) {
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            const int idx = t + 256 * q;
+            float4 v = f4(0.f);
+            if (idx < XV) {
+                const int rr = idx / (BI / 4), c4 = idx % (BI / 4);
+                const long long m = mrow + rr;
+                const int k = i0 + c4 * 4;
+                bool ok = m < mend && k < p.K;
+                long long src = m;
+                if (p.stem) {
+                    const long long hw = (long long)p.convH * p.convW;
+                    const long long img = m / hw;
+                    const int rem = (int)(m - img * hw);
+                    const int ho = rem / p.convW, wo = rem - ho * p.convW;
+                    float e[4];
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const int rq = k + qq, tap = rq / 3, ci = rq - tap * 3, kh = tap / 3, kw = tap - kh * 3;
+                        const int hi = 2 * ho + kh - p.stemPt, wi = 2 * wo + kw - p.stemPl;
+                        const bool okq = m < mend && rq < p.K && hi >= 0 && hi < p.stemH && wi >= 0 && wi < p.stemW;
+                        const float xv = p.x[okq ? ((img * p.stemH + hi) * p.stemW + wi) * 3 + ci : 0];
+                        e[qq] = okq ? fmaf(xv, p.stemScale, p.stemOffset) : 0.f;
+                    }
+                    xreg[q] = make_float4(e[0], e[1], e[2], e[3]);
+                    continue;
+                }
+                if (p.convH > 0 && ok) {
+                    const long long hw = (long long)p.convH * p.convW;
+                    const long long img = m / hw;
+                    const int rem = (int)(m - img * hw);
+                    const int hy = rem / p.convW + p.dh, wx = rem % p.convW + p.dw;
+                    ok = hy >= 0 && hy < p.convH && wx >= 0 && wx < p.convW;
+                    src = (img * p.convH + hy) * p.convW + wx;
+                }
+                {
+                    const int kk = ok ? k : 0;
+                    float4 s = f4(1.f), sh = f4(0.f);
+                    if (xaff) { s = ld4(p.xs + kk); sh = ld4(p.xt + kk); }
+                    v = view_affine4(ld4(p.x + (ok ? src * p.ldx + k : 0)), s, sh, xlo, xhi);
+                    if (!ok) v = f4(0.f);
+                }
+            }
+            xreg[q] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < YQ; ++q) {
+            const int idx = t + 256 * q;
+            float4 v = f4(0.f);
+            if (idx < YV) {
+                const int rr = idx / (BJ / 4), c4 = idx % (BJ / 4);
+                const long long m = mrow + rr;
+                const int n = j0 + c4 * 4;
+                {
+                    const bool ok = m < mend && n < p.N;
+                    const long long o = ok ? m * p.ldy + n : 0;
+                    const int nn = ok ? n : 0;
+                    float4 gs = f4(1.f), gt = f4(0.f), gk1 = f4(0.f), gk0 = f4(0.f);
+                    if (gaff) { gs = ld4(p.gs + nn); gt = ld4(p.gt + nn); gk1 = ld4(p.gk1 + nn); gk0 = ld4(p.gk0 + nn); }
+                    v = gview_apply4(ld4(p.g + o), ld4(yptr + o), gs, gt, gk1, gk0, yact);
+                    if (!ok) v = f4(0.f);
+                }
+            }
+            yreg[q] = v;
+        }
+    };
+    auto store_tiles_t = [&]() {
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            const int idx = t + 256 * q;
+            if (idx < XV) st4(Xs + idx * 4, xreg[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < YQ; ++q) {
+            const int idx = t + 256 * q;
+            if (idx < YV) st4(Ys + idx * 4, yreg[q]);
+        }
+    };
+
+
     f32x16 acc[WN];
 #pragma unroll
     for (int nt = 0; nt < WN; ++nt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
 
-    if (mbeg < mend) load_tiles(mbeg);
+    if (mbeg < mend) { if (RAW) load_tiles(mbeg); else load_tiles_t(mbeg); }
     for (long long mrow = mbeg; mrow < mend; mrow += BRT) {
         __syncthreads();
-        store_tiles();
+        if (RAW) store_tiles(); else store_tiles_t();
         __syncthreads();
-        if (mrow + BRT < mend) load_tiles(mrow + BRT);
+        if (mrow + BRT < mend) { if (RAW) load_tiles(mrow + BRT); else load_tiles_t(mrow + BRT); }
         const float* xa = Xs + (wr * RW + hh) * BI + wi * 32 + li;
         const float* yb = Ys + (wr * RW + hh) * BJ + li;
         // fragments of step st + 2 are read while the MFMAs of step st run (see gemm_rowA_kernel: no per-MFMA LDS round trip)
