@@ -115,6 +115,21 @@ int ssdseg_timing_reset(ssdseg_ctx* ctx);
 int ssdseg_timing_filter(ssdseg_ctx* ctx, const char* kernel);
 int ssdseg_timing_report(ssdseg_ctx* ctx, char* buf_host, size_t buf_len);
 /* hipGraph capture of a sequence of launches on the ctx stream (launch-bound inner loops) */
+/* Overlapped uploads (new: the reference feeds tf.data batches, NB03#cell8,16).  Pinned host memory and a copy stream
+ * per ctx: ssdseg_upload_async enqueues host -> device on the copy stream; ssdseg_upload_fence marks a point on the ctx stream
+ * (typically right after the kernels / copies that read a staging buffer) and after_fence != 0 keeps an upload behind the last
+ * such point -- but not behind work queued after it, which is what lets the upload of batch i+1 run under step i;
+ * ssdseg_upload_join makes the ctx stream wait for the uploads queued so far; ssdseg_upload_sync blocks the host until they are
+ * done (before the pinned source is overwritten). */
+int ssdseg_host_alloc(ssdseg_ctx* ctx, size_t bytes, void** out_host);
+int ssdseg_host_free(ssdseg_ctx* ctx, void* ptr_host);
+int ssdseg_upload_fence(ssdseg_ctx* ctx);
+/* src_host: pinned (ssdseg_host_alloc: the call returns at once) or ordinary pageable memory (the call returns when the
+ * runtime has staged it; the transfer still overlaps the kernels of the ctx stream) */
+int ssdseg_upload_async(ssdseg_ctx* ctx, void* dst, const void* src_host, size_t bytes, int after_fence);
+int ssdseg_upload_join(ssdseg_ctx* ctx);
+int ssdseg_upload_sync(ssdseg_ctx* ctx);
+
 int ssdseg_graph_begin(ssdseg_ctx* ctx);
 int ssdseg_graph_end(ssdseg_ctx* ctx, void** graph_exec_host);
 int ssdseg_graph_launch(ssdseg_ctx* ctx, void* graph_exec);

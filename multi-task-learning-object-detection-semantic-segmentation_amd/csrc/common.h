@@ -28,6 +28,9 @@ struct ssdseg_ctx {
     void* side_workspace;
     size_t side_workspace_bytes;
     bool side_ok, side_on, side_pending;
+    // copy stream (created on first use): host -> device staging uploads that overlap the running step (runtime.hip)
+    hipStream_t copy_stream;
+    hipEvent_t ev_copy_fork, ev_copy_join;
 };
 
 extern "C" {

@@ -213,6 +213,8 @@ int ssdseg_ctx_create(int device, void* stream, ssdseg_ctx** out_host) {
     c->side_workspace = nullptr;
     c->side_workspace_bytes = 0;
     c->side_ok = c->side_on = c->side_pending = false;
+    c->copy_stream = nullptr;
+    c->ev_copy_fork = c->ev_copy_join = nullptr;
     if (stream) {
         c->stream = (hipStream_t)stream;
         c->owns_stream = false;
@@ -281,6 +283,12 @@ int ssdseg_ctx_destroy(ssdseg_ctx* ctx) {
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->copy_stream) {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamDestroy(ctx->copy_stream);
+        (void)hipEventDestroy(ctx->ev_copy_fork);
+        (void)hipEventDestroy(ctx->ev_copy_join);
+    }
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
@@ -374,6 +382,68 @@ int ssdseg_memcpy_d2d(ssdseg_ctx* ctx, void* dst, const void* src, size_t bytes)
     SSDSEG_ARG(src != nullptr, 3);
     { int jrc = ssdseg_join(ctx); if (jrc) return jrc; }
     SSDSEG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+}
+
+// ---- overlapped uploads: pinned host memory + a copy stream ordered against the main stream by two events
+static int copy_stream_of(ssdseg_ctx* ctx) {
+    if (ctx->copy_stream != nullptr) return 0;
+    SSDSEG_HIP(hipSetDevice(ctx->device));
+    SSDSEG_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    SSDSEG_HIP(hipEventCreateWithFlags(&ctx->ev_copy_fork, hipEventDisableTiming));
+    SSDSEG_HIP(hipEventCreateWithFlags(&ctx->ev_copy_join, hipEventDisableTiming));
+    return 0;
+}
+
+int ssdseg_host_alloc(ssdseg_ctx* ctx, size_t bytes, void** out_host) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(bytes > 0, 2);
+    SSDSEG_ARG(out_host != nullptr, 3);
+    SSDSEG_HIP(hipSetDevice(ctx->device));
+    SSDSEG_HIP(hipHostMalloc(out_host, bytes, hipHostMallocDefault));
+    return 0;
+}
+
+int ssdseg_host_free(ssdseg_ctx* ctx, void* ptr_host) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    if (ptr_host) SSDSEG_HIP(hipHostFree(ptr_host));
+    return 0;
+}
+
+int ssdseg_upload_fence(ssdseg_ctx* ctx) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(!ctx->capturing, 1);
+    int rc = copy_stream_of(ctx);
+    if (rc) return rc;
+    SSDSEG_HIP(hipEventRecord(ctx->ev_copy_fork, ctx->stream));
+    return 0;
+}
+
+int ssdseg_upload_async(ssdseg_ctx* ctx, void* dst, const void* src_host, size_t bytes, int after_fence) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    if (bytes == 0) return 0;
+    SSDSEG_ARG(dst != nullptr, 2);
+    SSDSEG_ARG(src_host != nullptr, 3);
+    SSDSEG_ARG(!ctx->capturing, 1);
+    int rc = copy_stream_of(ctx);
+    if (rc) return rc;
+    // the destination may still be read by main-stream work queued BEFORE the last fence (not by what came after it)
+    if (after_fence) SSDSEG_HIP(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_copy_fork, 0));
+    SSDSEG_HIP(hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+    return 0;
+}
+
+int ssdseg_upload_join(ssdseg_ctx* ctx) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    if (ctx->copy_stream == nullptr) return 0;
+    SSDSEG_HIP(hipEventRecord(ctx->ev_copy_join, ctx->copy_stream));
+    SSDSEG_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_copy_join, 0));
+    return 0;
+}
+
+int ssdseg_upload_sync(ssdseg_ctx* ctx) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    if (ctx->copy_stream != nullptr) SSDSEG_HIP(hipStreamSynchronize(ctx->copy_stream));
     return 0;
 }
 

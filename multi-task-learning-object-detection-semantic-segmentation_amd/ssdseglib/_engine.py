@@ -18,6 +18,7 @@ reverse launch order (deterministic).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -1244,6 +1245,50 @@ def run_train_on_batch(model: K.Model, x, y) -> Dict[str, float]:
     return eng.losses()
 
 
+class _BatchStager:
+    """Hands the NEXT batch to the device while the current step runs (fit's input side).
+
+    The host arrays are uploaded on the context's copy stream into device staging buffers while the GPU computes the current
+    step (the host thread blocks in the copy -- the runtime pipelines pageable memory through its own pinned buffers at
+    ~45 GB/s -- but it has nothing else to do until the step's losses are ready); at the start of the step that uses them
+    the main stream waits for that upload and copies staging -> the engine's input / target buffers (device to device,
+    ~0.3 ms for 285 MB).  The engine's own buffers cannot be the upload target: the running step still reads them (the mask
+    targets until the end of the backward pass).  A first version copied into pinned buffers of its own: that host memcpy
+    (285 MB, one thread) took as long as the step and bought nothing."""
+
+    def __init__(self, eng: "Engine"):
+        self.eng = eng
+        self.ctx = eng.ctx
+        self.dst = [("__input__", eng.input_store.buf)]
+        for name, op, kind in eng._loss_names:
+            self.dst.append((name, op.y_true if kind == "mask" else (op.y_labels if kind == "conf" else op.y_boxes)))
+        self.staging = [self.ctx.empty(d.shape) for _, d in self.dst]
+        self.staged = False
+        self._keep = None      # the host arrays of the upload in flight
+
+    def stage(self, x, y) -> bool:
+        """host side, while the GPU is busy with the current step: fill the pinned buffers, enqueue the uploads"""
+        arrays = [x] + [y[name] for name, _ in self.dst[1:]]
+        if any(isinstance(a, H.DeviceBuffer) for a in arrays) or any(int(np.prod(np.shape(a))) != st.size for a, st in zip(arrays, self.staging)):
+            return False
+        arrays = [np.ascontiguousarray(a, dtype=np.float32) for a in arrays]   # no copy for float32 C-contiguous batches
+        self.ctx.upload_sync()
+        for a, st in zip(arrays, self.staging):
+            self.ctx.upload_async(st, a, after_fence=True)   # behind the last consume(), under the step queued after it
+        self._keep = arrays
+        self.staged = True
+        return True
+
+    def consume(self):
+        """device side, at the start of the step: staging -> the engine's buffers"""
+        assert self.staged
+        self.ctx.upload_join()
+        for (_, d), st in zip(self.dst, self.staging):
+            d.copy_from(st)
+        self.ctx.upload_fence()                     # from here on the staging buffers may be overwritten
+        self.staged = False
+
+
 class History:
     def __init__(self):
         self.history: Dict[str, List[float]] = {}
@@ -1254,15 +1299,35 @@ def run_fit(model: K.Model, data, epochs=1, validation_data=None, verbose=0) -> 
     """model.fit(ds, epochs, validation_data, verbose) (NB03#cell16): the last partial batch is kept (its own batch
     statistics and mining pool); per-epoch means weighted by batch size, Keras history keys."""
     hist = History()
+    overlap = os.environ.get("SSDSEG_FIT_OVERLAP", "1") != "0"
     for epoch in range(epochs):
         sums: Dict[str, float] = {}
         seen = 0
-        for x, y in _batches(data):
-            logs = run_train_on_batch(model, x, y)
-            n = np.asarray(x).shape[0]
+        it = iter(_batches(data))
+        cur = next(it, None)
+        staged_for = None      # id of the batch whose upload is in flight, and its stager
+        while cur is not None:
+            x, y = cur
+            n = int(np.shape(x)[0]) if not isinstance(x, H.DeviceBuffer) else x.shape[0]
+            eng = engine_for(model, n, True)
+            if staged_for is not None and staged_for[0] is cur:
+                staged_for[1].consume()
+                eng.train_step(optimizer=model._compiled.get("optimizer"))
+            else:
+                eng.train_step(np.asarray(x, np.float32) if not isinstance(x, H.DeviceBuffer) else x, y, optimizer=model._compiled.get("optimizer"))
+            # the step is queued; everything below runs on the host while the GPU works on it
+            nxt = next(it, None)
+            staged_for = None
+            if overlap and nxt is not None and nxt[1] is not None and not isinstance(nxt[0], H.DeviceBuffer) and int(np.shape(nxt[0])[0]) == n:
+                stager = eng.__dict__.setdefault("_stager", None) or _BatchStager(eng)
+                eng._stager = stager
+                if stager.stage(nxt[0], nxt[1]):
+                    staged_for = (nxt, stager)
+            logs = eng.losses()
             for k, v in logs.items():
                 sums[k] = sums.get(k, 0.0) + v * n
             seen += n
+            cur = nxt
         logs = {k: v / max(seen, 1) for k, v in sums.items()}
         if validation_data is not None:
             vs: Dict[str, float] = {}

@@ -61,6 +61,12 @@ _SIGNATURES = {
     "ssdseg_timing_reset": [_vp],
     "ssdseg_timing_filter": [_vp, C.c_char_p],
     "ssdseg_timing_report": [_vp, C.c_char_p, _sz],
+    "ssdseg_host_alloc": [_vp, _sz, C.POINTER(_vp)],
+    "ssdseg_host_free": [_vp, _vp],
+    "ssdseg_upload_fence": [_vp],
+    "ssdseg_upload_async": [_vp, _vp, _vp, _sz, _i],
+    "ssdseg_upload_join": [_vp],
+    "ssdseg_upload_sync": [_vp],
     "ssdseg_graph_begin": [_vp],
     "ssdseg_graph_end": [_vp, C.POINTER(_vp)],
     "ssdseg_graph_launch": [_vp, _vp],
@@ -159,6 +165,29 @@ def _ptr(x) -> Optional[int]:
     if isinstance(x, DeviceBuffer):
         return x.ptr
     return int(x)
+
+
+class PinnedBuffer:
+    """Page-locked host memory (hipHostMalloc) exposed as a NumPy array: the source of overlapped uploads."""
+
+    def __init__(self, ctx: "Context", shape, dtype=np.float32):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        out = C.c_void_p()
+        _check(ctx.lib.ssdseg_host_alloc(ctx.handle, max(self.nbytes, 4), C.byref(out)), "ssdseg_host_alloc")
+        self.ptr = out.value
+        self.array = np.frombuffer((C.c_char * self.nbytes).from_address(self.ptr), dtype=self.dtype).reshape(self.shape)
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None) and self.ctx.handle:
+                self.array = None
+                self.ctx.lib.ssdseg_host_free(self.ctx.handle, C.c_void_p(self.ptr))
+        except Exception:
+            pass
+        self.ptr = None
 
 
 class DeviceBuffer:
@@ -338,6 +367,23 @@ class Context:
         return out
 
     # ---- hipGraph capture
+    # ---- overlapped uploads (copy stream)
+    def upload_async(self, dst: "DeviceBuffer", src, after_fence: bool = True):
+        """src: a PinnedBuffer (truly asynchronous) or a C-contiguous NumPy array (the call returns when the runtime has staged
+        it; the copy still runs on the copy stream, concurrently with the kernels of the main stream)"""
+        assert dst.nbytes == src.nbytes
+        ptr = src.ptr if isinstance(src, PinnedBuffer) else src.ctypes.data
+        _check(self.lib.ssdseg_upload_async(self.handle, dst.ptr, ptr, dst.nbytes, 1 if after_fence else 0), "ssdseg_upload_async")
+
+    def upload_fence(self):
+        _check(self.lib.ssdseg_upload_fence(self.handle), "ssdseg_upload_fence")
+
+    def upload_join(self):
+        _check(self.lib.ssdseg_upload_join(self.handle), "ssdseg_upload_join")
+
+    def upload_sync(self):
+        _check(self.lib.ssdseg_upload_sync(self.handle), "ssdseg_upload_sync")
+
     def graph_begin(self):
         _check(self.lib.ssdseg_graph_begin(self.handle), "ssdseg_graph_begin")
 

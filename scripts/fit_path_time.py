@@ -31,6 +31,14 @@ for _ in range(K):
     logs = model.train_on_batch(x, y)      # uploads x and y, runs the step, downloads the three (B,) losses
 dt = (time.perf_counter() - t0) / K
 print(f"fit path (host arrays in, losses out): {dt * 1e3:.1f} ms/step = {batch / dt:.0f} images/sec; loss {logs['loss']:.4f}")
+for mode in ("0", "1"):
+    os.environ["SSDSEG_FIT_OVERLAP"] = mode
+    model.fit([(x, y)] * 3, epochs=1)
+    t0 = time.perf_counter()
+    model.fit([(x, y)] * K, epochs=1)
+    dtf = (time.perf_counter() - t0) / K
+    print(f"fit(), SSDSEG_FIT_OVERLAP={mode} ({'next batch staged on the copy stream under the running step' if mode == '1' else 'synchronous hand-over'}): "
+          f"{dtf * 1e3:.1f} ms/step = {batch / dtf:.0f} images/sec")
 eng = E.engine_for(model, batch, True)
 t0 = time.perf_counter()
 for _ in range(K):

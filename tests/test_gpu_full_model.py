@@ -177,3 +177,29 @@ def test_inference_model_and_keras_surface(ctx, rng):
         for a, b in zip(model.layers, fresh.layers):
             for wa, wb in zip(a.get_weights(), b.get_weights()):
                 assert np.array_equal(wa, wb)
+
+
+def test_fit_overlapped_upload_equals_synchronous(ctx, rng, monkeypatch):
+    """fit() stages batch i+1 on the copy stream while step i runs (pinned host buffers -> device staging -> the engine's
+    buffers at the start of the next step): the history must be bit-identical to the synchronous hand-over, also across a
+    smaller last batch (which takes the synchronous path: another engine)"""
+    import ssdseglib
+    from ssdseglib import _engine as E
+    E.set_default_context(ctx)
+    batches = []
+    for bsz in (3, 3, 3, 2):
+        boxes, builder, _ = build()
+        enc, gts, targets = make_targets(rng, boxes, bsz)
+        batches.append((rng.integers(0, 256, (bsz,) + SHAPE).astype(np.float32), targets))
+    hist = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SSDSEG_FIT_OVERLAP", mode)
+        boxes, builder, model = build(seed=5)
+        model.compile(optimizer=ssdseglib.optimizers.Adam(learning_rate=1e-3),
+                      loss={'output-mask': ssdseglib.losses.cross_entropy(classes_weights=CW), 'output-labels': ssdseglib.losses.confidence_loss,
+                            'output-boxes': ssdseglib.losses.localization_loss},
+                      loss_weights={'output-mask': 1.0, 'output-labels': 1.0, 'output-boxes': 1.0})
+        hist[mode] = model.fit(batches, epochs=2, verbose=0).history
+    assert hist["1"].keys() == hist["0"].keys()
+    for k in hist["1"]:
+        assert hist["1"][k] == hist["0"][k], (k, hist["1"][k], hist["0"][k])
