@@ -8,4 +8,5 @@ from . import models
 from . import losses
 from . import metrics
 from . import datacoder
+from . import evaluators
 from . import optimizers

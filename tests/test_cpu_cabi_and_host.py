@@ -97,3 +97,29 @@ def test_metrics_and_loss_factories_shapes():
     assert fn.loss_kind == "cross_entropy" and fn.classes_weights == (0.05, 0.575, 0.135, 0.24)
     opt = ssdseglib.optimizers.Adam(learning_rate=1e-4)
     assert (opt.learning_rate, opt.beta_1, opt.beta_2, opt.epsilon) == (1e-4, 0.9, 0.999, 1e-7)
+
+
+def test_offline_evaluators_hand_worked(tmp_path):
+    """ssdseglib.evaluators (reference evaluators.py:65-247) on a case small enough to do by hand"""
+    import ssdseglib
+    from PIL import Image
+    # two samples; class 1 has 2 ground-truth boxes in total, class 2 has 1
+    f0, f1 = tmp_path / "a.csv", tmp_path / "b.csv"
+    f0.write_text("1,10,10,29,29\r\n2,50,50,69,69\r\n")
+    f1.write_text("1,0,0,19,19\r\n")
+    labels = np.array([[1, 1, 0], [1, 2, 0]])                       # 0 = background: ignored
+    conf = np.array([[0.9, 0.6, 0.99], [0.8, 0.7, 0.5]], np.float32)
+    boxes = np.array([[[10, 10, 29, 29], [100, 100, 119, 119], [0, 0, 5, 5]],          # exact hit, miss, (background)
+                      [[0, 0, 19, 19], [0, 0, 19, 19], [0, 0, 1, 1]]], np.float32)   # exact hit, wrong label for that box
+    ap = ssdseglib.evaluators.average_precision_object_detection(labels, conf, boxes, 0.5, [str(f0), str(f1)], [0, 1, 2], 0)
+    # class 1 ranked by confidence: 0.9 TP, 0.8 TP, 0.6 FP -> precision (1, 1, 2/3), recall (0.5, 1, 1) -> area 0.5 * 1 = 0.5
+    assert abs(ap[1] - 0.5) < 1e-6 and ap[2] == 0.0 and 0 not in ap
+    iou = ssdseglib.evaluators._iou_boxes_pred_vs_true([1], [[0, 0, 9, 9]], [1, 2], [[5, 0, 14, 9], [0, 0, 9, 9]])
+    assert np.allclose(iou, [[50 / 150, 0.0]], atol=1e-6)           # 5x10 overlap of two 10x10 boxes; label mismatch -> 0
+    # segmentation: 2x2 image, mask classes [[0, 1], [1, 2]], prediction = the one-hot truth except one pixel split 50/50
+    m = tmp_path / "m.png"
+    Image.fromarray(np.array([[0, 1], [1, 2]], np.uint8)).save(m)
+    pred = np.eye(3, dtype=np.float32)[np.array([[0, 1], [1, 2]])][None]
+    pred[0, 0, 1] = [0.5, 0.5, 0.0]
+    got = ssdseglib.evaluators.jaccard_iou_semantic_segmentation(pred, [str(m)], [0, 1, 2], 0)
+    assert abs(got[1] - 1.5 / 2.0) < 1e-6 and abs(got[2] - 1.0) < 1e-6 and 0 not in got   # class 1: inter 1.5, total 3.5
