@@ -365,7 +365,9 @@ int dw_bwd_choice() {
 bool dw_fwd_use_march(int n, int h, int w, int c, int dilation) {
     const char* e = getenv("SSDSEG_DW_FWD");
     const bool lds = e != nullptr && !strcmp(e, "lds");
-    return !lds && dilation == 1 && (long long)n * h * w * c < (1LL << 30);
+    const char* atr = getenv("SSDSEG_DW_ATROUS");   // "gather": direct-gather kernels for the dilated convs
+    const bool atrous_ok = !(atr != nullptr && !strcmp(atr, "gather"));
+    return !lds && (dilation == 1 || atrous_ok) && (long long)n * h * w * c < (1LL << 30);
 }
 
 struct BnFuse {   // BatchNorm-backward reduction of the layer feeding this depthwise conv, fused into its backward
@@ -499,7 +501,7 @@ int ssdseg_dwconv_parts(int n, int h, int w, int c, int stride, int dilation, in
     dw_geometry(n, h, w, c, stride, dilation, &g, &l);
     if (dw_fwd_use_march(n, h, w, c, dilation)) {
         March2Geom mg;
-        *nparts_host = (int)march_fwd_geometry(n, h, w, c, g.ho, g.wo, stride, &mg).grid.x;             // column-marching kernels
+        *nparts_host = (int)march_fwd_geometry(n, h, w, c, g.ho, g.wo, stride, &mg, dilation).grid.x;   // column-marching kernels
     } else if (dilation == 1) {
         *nparts_host = (int)(stride == 1 ? lds_launch<1>(g) : lds_launch<2>(g)).grid.x;                  // LDS-tiled kernels
     } else {
@@ -530,14 +532,15 @@ int ssdseg_dwconv_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, fl
     const double cost_flops = 18.0 * n * g.ho * g.wo * c;
     if (dw_fwd_use_march(n, h, wdt, c, dilation)) {
         March2Geom mg;
-        const MarchLaunch ml = march_fwd_geometry(n, h, wdt, c, g.ho, g.wo, stride, &mg);
-#define DW_FWD_MARCH(S_, PT_, PL_) \
-    SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_fwd_march_kernel<S_, PT_, PL_>), ml.grid, ml.block, ml.lds, mg, v, w, y, stats)
-        if (stride == 1) DW_FWD_MARCH(1, 1, 1);
-        else if (g.pt == 0 && g.pl == 0) DW_FWD_MARCH(2, 0, 0);
-        else if (g.pt == 0) DW_FWD_MARCH(2, 0, 1);
-        else if (g.pl == 0) DW_FWD_MARCH(2, 1, 0);
-        else DW_FWD_MARCH(2, 1, 1);
+        const MarchLaunch ml = march_fwd_geometry(n, h, wdt, c, g.ho, g.wo, stride, &mg, dilation);
+#define DW_FWD_MARCH(S_, PT_, PL_, DIL_) \
+    SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_fwd_march_kernel<S_, PT_, PL_, DIL_>), ml.grid, ml.block, ml.lds, mg, v, w, y, stats)
+        if (dilation > 1) DW_FWD_MARCH(1, 1, 1, true);
+        else if (stride == 1) DW_FWD_MARCH(1, 1, 1, false);
+        else if (g.pt == 0 && g.pl == 0) DW_FWD_MARCH(2, 0, 0, false);
+        else if (g.pt == 0) DW_FWD_MARCH(2, 0, 1, false);
+        else if (g.pl == 0) DW_FWD_MARCH(2, 1, 0, false);
+        else DW_FWD_MARCH(2, 1, 1, false);
 #undef DW_FWD_MARCH
     } else if (dilation == 1 && stride == 1) {
         const LdsLaunch ll = lds_launch<1>(g);

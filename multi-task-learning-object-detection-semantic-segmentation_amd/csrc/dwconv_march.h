@@ -292,6 +292,7 @@ struct March2Stage {   // raw loads of one step: dy row r (3 columns of g, y) an
 struct March2Geom {
     int n, h, w, c, ho, wo;
     int rows, chunks, wstrips, cb, spb, sblocks, sgroups;   // as MarchGeom, over the OUTPUT rows / 2-column output strips
+    int dil;                                                // forward DIL kernels: see MarchGeom::dil
 };
 
 // ACC: dx += result.  The old values are fetched WITH the step's other loads (one step ahead); read inline at the store they
@@ -488,7 +489,8 @@ __global__ void __launch_bounds__(MARCH_MAX_THREADS) __attribute__((amdgpu_waves
 // S = 2: 2 output columns (5 input columns), two new input rows per output row, the third is next step's first.
 // BN statistics (sum, sumsq of the raw output) stay in registers and leave as one partial row per block.
 // `gm` is a March2Geom in both cases (h, w input; ho, wo output; strips over output columns).
-template <int S, int PT, int PL>
+// DIL (S == 1, PT == PL == 1): atrous conv as dil^2 interleaved dense convs over the sub-grids, as in the backward kernel
+template <int S, int PT, int PL, bool DIL = false>
 __global__ void __launch_bounds__(MARCH_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) dw_fwd_march_kernel(March2Geom gm, ViewDev in, const float* __restrict__ wgt, float* __restrict__ y,
                                                             float* __restrict__ stats) {
     constexpr int OC = S == 1 ? 4 : 2;        // output columns per thread
@@ -499,12 +501,20 @@ __global__ void __launch_bounds__(MARCH_MAX_THREADS) __attribute__((amdgpu_waves
     const int t = threadIdx.x;
     const int sp = t / gm.cb, cl = t - sp * gm.cb;
     const int ch = bpos.y * gm.cb + cl;
+    static_assert(!DIL || (S == 1 && PT == 1 && PL == 1), "dilated march: stride 1, SAME");
     int sb = bpos.x;
     const int sg = sb % gm.sgroups; sb /= gm.sgroups;
-    const int rc = sb % gm.chunks;
-    const int img = sb / gm.chunks;
+    const int rc = sb % gm.chunks; sb /= gm.chunks;
+    const int dil = DIL ? gm.dil : 1;
+    const int sub = DIL ? sb % (dil * dil) : 0;
+    const int img = DIL ? sb / (dil * dil) : sb;
+    const int ga = sub / dil, gb = sub - ga * dil;
+    // height / width of this sub-grid (input == output for the dilated case); the dense conv is the 1x1 grid
+    const int hh = DIL ? (gm.h - ga + dil - 1) / dil : gm.h, ww = DIL ? (gm.w - gb + dil - 1) / dil : gm.w;
+    const int hho = DIL ? hh : gm.ho, wwo = DIL ? ww : gm.wo;
     const int ws = sg * gm.spb + sp;
-    const bool active = sp < gm.spb && ch < gm.c && ws < gm.wstrips && bpos.x < gm.sblocks;
+    const bool active = sp < gm.spb && ch < gm.c && ws < gm.wstrips && bpos.x < gm.sblocks &&
+                        (!DIL || (ws * OC < wwo && rc * gm.rows < hho));
     const int chs = ch < gm.c ? ch : 0;
     const bool iaff = in.scale != nullptr;
     const float ilo = act_lo(in.act), ihi = act_hi(in.act);
@@ -517,17 +527,17 @@ __global__ void __launch_bounds__(MARCH_MAX_THREADS) __attribute__((amdgpu_waves
     if (active) {
         const int wo0 = ws * OC, wi0 = wo0 * S - PL;
         const int r0 = rc * gm.rows;
-        const int r1 = r0 + gm.rows < gm.ho ? r0 + gm.rows : gm.ho;
-        const unsigned ibase = (((unsigned)img * gm.h * gm.w) * gm.c + ch) * 4u;
-        const unsigned obase = (((unsigned)img * gm.ho * gm.wo) * gm.c + ch) * 4u;
-        const unsigned irow = (unsigned)gm.w * gm.c * 4u, orow = (unsigned)gm.wo * gm.c * 4u, ocol = (unsigned)gm.c * 4u;
+        const int r1 = r0 + gm.rows < hho ? r0 + gm.rows : hho;
+        const unsigned ibase = ((((unsigned)img * gm.h + ga) * gm.w + gb) * gm.c + ch) * 4u;
+        const unsigned obase = ((((unsigned)img * gm.ho + ga) * gm.wo + gb) * gm.c + ch) * 4u;
+        const unsigned irow = (unsigned)dil * gm.w * gm.c * 4u, orow = (unsigned)dil * gm.wo * gm.c * 4u, ocol = (unsigned)dil * gm.c * 4u;
         bool xok[IC];
         unsigned xoff[IC];
 #pragma unroll
         for (int b = 0; b < IC; ++b) {
             const int col = wi0 + b;
-            xok[b] = col >= 0 && col < gm.w;
-            xoff[b] = (unsigned)(xok[b] ? col : 0) * gm.c * 4u;
+            xok[b] = col >= 0 && col < ww;
+            xoff[b] = (unsigned)(xok[b] ? col : 0) * ocol;   // (input column stride == output column stride: dil * c floats)
         }
         struct Stage { float x[NR][IC]; };
         // the NR new input rows of output row r: S=1: row r + 1 - PT (= r+1-1 .. window rows r-PT, r-PT+1, r-PT+2);
@@ -537,14 +547,14 @@ __global__ void __launch_bounds__(MARCH_MAX_THREADS) __attribute__((amdgpu_waves
 #pragma unroll
             for (int q = 0; q < NR; ++q) {
                 int row = first_new(r) + q;
-                row = row < 0 ? 0 : (row > gm.h - 1 ? gm.h - 1 : row);
+                row = row < 0 ? 0 : (row > hh - 1 ? hh - 1 : row);
                 const unsigned rb = ibase + (unsigned)row * irow;
 #pragma unroll
                 for (int b = 0; b < IC; ++b) s.x[q][b] = ldg_b(in.x, rb + xoff[b]);
             }
         };
         auto activate = [&](int row, const float (&raw)[IC], float (&a)[IC]) {
-            const bool rok = row >= 0 && row < gm.h;
+            const bool rok = row >= 0 && row < hh;
 #pragma unroll
             for (int b = 0; b < IC; ++b) {
                 const float z = fminf(fmaxf(fmaf(is, raw[b], it), ilo), ihi);
@@ -580,7 +590,7 @@ __global__ void __launch_bounds__(MARCH_MAX_THREADS) __attribute__((amdgpu_waves
                 for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
                     for (int kw = 0; kw < 3; ++kw) acc = fmaf(wa[kh][j * S + kw], wk[kh * 3 + kw], acc);
-                if (wo0 + j < gm.wo) {
+                if (wo0 + j < wwo) {
                     *reinterpret_cast<float*>(reinterpret_cast<char*>(y) + (ob + (unsigned)j * ocol)) = acc;
                     ssum += acc;
                     ssq = fmaf(acc, acc, ssq);
@@ -619,8 +629,10 @@ __global__ void __launch_bounds__(MARCH_MAX_THREADS) __attribute__((amdgpu_waves
 }
 
 // forward geometry: strips of OC output columns
-inline MarchLaunch march_fwd_geometry(int n, int h, int w, int c, int ho, int wo, int stride, March2Geom* g) {
-    g->n = n; g->h = h; g->w = w; g->c = c; g->ho = ho; g->wo = wo;
+inline MarchLaunch march_fwd_geometry(int n, int h, int w, int c, int ho, int wo, int stride, March2Geom* g, int dil = 1) {
+    g->n = n; g->h = h; g->w = w; g->c = c; g->ho = ho; g->wo = wo; g->dil = dil;
+    n *= dil * dil;                            // (dil > 1: stride 1, ho == h, wo == w; the largest sub-grid sets the geometry)
+    ho = cdiv(ho, dil); wo = cdiv(wo, dil);
     g->wstrips = cdiv(wo, stride == 1 ? 4 : 2);
     int cchunks;
     march_split(c, g->wstrips, &g->cb, &g->spb, &cchunks);
@@ -640,7 +652,7 @@ inline MarchLaunch march_fwd_geometry(int n, int h, int w, int c, int ho, int wo
 }
 
 inline MarchLaunch march2_geometry(int n, int h, int w, int c, int ho, int wo, March2Geom* g) {
-    g->n = n; g->h = h; g->w = w; g->c = c; g->ho = ho; g->wo = wo;
+    g->n = n; g->h = h; g->w = w; g->c = c; g->ho = ho; g->wo = wo; g->dil = 1;
     g->wstrips = cdiv(wo, 2);
     int cchunks;
     march_split(c, g->wstrips, &g->cb, &g->spb, &cchunks);
