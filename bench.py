@@ -249,6 +249,28 @@ def pmc_traffic(kernel: str, workload: str, batch: int):
     return round(row["hbm_bytes_per_launch"], 1), os.path.relpath(files[-1], here)
 
 
+def achievable_ceiling(bound: str):
+    """the committed micro-benchmark figure for this bound (scripts/micro/*.hip -> profiles/r*_microbench.txt), or None"""
+    import glob
+    import re
+    here = os.path.dirname(os.path.abspath(__file__))
+    pat = "r*_mfma_f32_peak_microbench.txt" if bound == "mfma" else "r*_hbm_streaming_microbench.txt"
+    files = sorted(glob.glob(os.path.join(here, "profiles", pat)))
+    if not files:
+        return None
+    try:
+        text = open(files[-1]).read()
+    except OSError:
+        return None
+    vals = [float(v) for v in re.findall(r"([\d.]+) (?:TFLOP/s|TB/s)", text)]
+    if not vals:
+        return None
+    if bound == "mfma":
+        return {"value": max(vals), "unit": "TFLOP/s", "what": "register-only v_mfma_f32_32x32x2_f32 loop", "source": os.path.relpath(files[-1], here)}
+    return {"value": round(max(vals) * 1e3, 1), "unit": "GB/s", "what": "best of the trivial float4 streams (copy, 3 reads : 1 write) over 1 GiB tensors",
+            "source": os.path.relpath(files[-1], here)}
+
+
 def nms_boxes_per_sec(ctx, batch, reps=20):
     """Secondary metric of BASELINE.json ("NMS boxes/sec"): B*9600 / t for box decode + combined NMS
     (4 classes incl. background, <= 4 per class, <= 10 per image, NB03#cell18 thresholds) on synthetic head outputs."""
@@ -411,6 +433,10 @@ def main():
                 "share_of_kernel_time": round(survey[dominant]["ms"] / total_ms, 4),
                 "algorithmic_bytes_per_launch": dom["bytes"] / dom["count"], "flops_per_launch": dom["flops"] / dom["count"],
             }
+            ach = achievable_ceiling(bound)
+            if ach is not None:
+                # extra context, not the contract's `peak`: what a trivial micro-benchmark sustains on this chip (committed summary)
+                out["roofline"]["achievable_ceiling"] = ach
             if dominant in isolated and isolated[dominant]["count"] > 0:
                 iso = isolated[dominant]
                 iso_ms = iso["ms"] / iso["count"]
