@@ -48,17 +48,17 @@ def default_boxes():
 
 
 def build_models(seed=1993, kind="mobilenetv2"):
-    """-> (boxes, builder) for the NB03 configuration; kind "shufflenetv2" = SURVEY.md 8(d) config 5 with model_size '1.5x'
-    (additional depthwise convolution, residual connections; the reference's quirk Q1 -- heads built with ReLU(max_value=0.0) --
-    kept bug-compatible).  '1x' / '2x' have 58- / 122-channel branches; the kernels take channel counts that are multiples of 4
-    (16-byte channel vectors), so those two sizes are refused by the engine -- '0.5x' and '1.5x' run."""
+    """-> (boxes, builder) for the NB03 configuration; kind "shufflenetv2" = SURVEY.md 8(d) config 5: model_size '1x', additional
+    depthwise convolution, residual connections; the reference's quirk Q1 -- heads built with ReLU(max_value=0.0) -- kept
+    bug-compatible.  ('1x' splits its stage-2 tensors into 58-channel branches; the engine runs those units on zero-padded
+    60-channel tensors and weights.)"""
     import ssdseglib
     from ssdseglib import _graph as K
     K.set_seed(seed)
     boxes = default_boxes()
     if kind == "shufflenetv2":
         return boxes, ssdseglib.models.ShuffleNetV2SsdSegBuilder(
-            input_image_shape=IMAGE_SHAPE, model_size='1.5x', use_additional_depthwise_convolution=True, use_residual_connections=True,
+            input_image_shape=IMAGE_SHAPE, model_size='1x', use_additional_depthwise_convolution=True, use_residual_connections=True,
             number_of_boxes_per_point=[6, 6, 6, 6], number_of_classes=4,
             center_x_boxes_default=boxes.get_boxes_coordinates_center_x('ssd'), center_y_boxes_default=boxes.get_boxes_coordinates_center_y('ssd'),
             width_boxes_default=boxes.get_boxes_coordinates_width('ssd'), height_boxes_default=boxes.get_boxes_coordinates_height('ssd'),
@@ -174,7 +174,7 @@ class FullStep:
 
 class ShuffleNetStep(FullStep):
     """configs[4] per GPU: the same train step on the ShuffleNetV2 1x variant (channel shuffle / split / max-pool kernels)"""
-    workload = ("BASELINE.json configs[4] (per-GPU share): full ShuffleNetV2-1.5x-SSDLite-DeepLabV3+ train step (additional depthwise "
+    workload = ("BASELINE.json configs[4] (per-GPU share): full ShuffleNetV2-1x-SSDLite-DeepLabV3+ train step (additional depthwise "
                 "convolution + residual connections; anchor encode + fwd + 3 losses + bwd (+all-reduce) + Adam), batch 32/GPU, 480x640x3, "
                 "9600 anchors, 4 classes; reference quirk Q1 (heads' ReLU max_value 0.0) kept bug-compatible")
     kind = "shufflenetv2"

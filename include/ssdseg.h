@@ -337,6 +337,15 @@ int ssdseg_maxpool3x3s2_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, const float*
  * inverse != 0 applies the inverse permutation (gradient path; pass an identity view). */
 int ssdseg_channel_shuffle(ssdseg_ctx* ctx, const ssdseg_view* in, int ldi, float* out, int ldo, int m, int c, int groups,
                            int inverse);
+/* General channel re-indexing: out[m][j] = table[j] >= 0 ? view(in)[m][table[j]] : 0 (+ previous contents when accumulate).
+ * ShuffleNetV2 '1x' / '2x' split their stage-2 tensors into 58 / 122 channels; inside those units the branch tensors are
+ * zero-padded to multiples of 4 and Split (models.py:573), the channel shuffle (models.py:497-503) and their gradients are
+ * table lookups between the packed and the padded layouts.  table: device int32 [c_out]. */
+int ssdseg_channel_gather(ssdseg_ctx* ctx, const ssdseg_view* in, int ldi, float* out, int ldo, long long m, int c_out,
+                          const int32_t* table, int accumulate);
+/* rows x cols block copy between row-major matrices of different leading dimension: parameters between their exact Keras
+ * shapes (flat bucket) and the zero-padded shapes of those units */
+int ssdseg_copy2d(ssdseg_ctx* ctx, float* dst, int ldd, const float* src, int lds, int rows, int cols);
 /* g *= act'(x) in place: backward of a ReLU that follows an Add (ShuffleNetV2 basic unit, models.py:593-595) */
 int ssdseg_act_bwd(ssdseg_ctx* ctx, float* g, int ldg, const float* x, int ldx, int m, int c, int act);
 

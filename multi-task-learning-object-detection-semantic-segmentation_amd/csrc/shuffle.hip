@@ -120,6 +120,41 @@ void pool_geom(int n, int h, int w, int c, PoolGeom* g) {
     same_pad(w, 3, 2, 1, &g->wo, &g->pl);
 }
 
+
+// out[m][j] = table[j] >= 0 ? act(s * in[m][table[j]] + t) : 0   (+ previous contents).  The general channel re-indexing
+// behind the ShuffleNetV2 sizes whose branches are not multiples of 4 channels wide ('1x': 58, '2x': 122): inside a unit the
+// branch tensors are zero-padded to the next multiple of 4, and split / shuffle / their gradients become table lookups
+// between the packed (116-wide) and the padded (60 + 60) layouts.  One thread per output element, scalar accesses.
+__global__ void channel_gather_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                      int ldi, float* __restrict__ out, int ldo, long long m, int c_out, const int* __restrict__ table,
+                                      int accumulate) {
+    const long long total = m * c_out;
+    const bool aff = scale != nullptr;
+    const float lo = act_lo(act), hi = act_hi(act);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(i % c_out);
+        const long long row = i / c_out;
+        const int src = table[j];
+        float v = 0.f;
+        if (src >= 0) {
+            v = x[row * ldi + src];
+            v = fminf(fmaxf(aff ? fmaf(scale[src], v, shift[src]) : v, lo), hi);
+        }
+        float* o = out + row * ldo + j;
+        *o = accumulate ? *o + v : v;
+    }
+}
+
+// dst[r][c] = src[r][c] for a rows x cols block of two row-major matrices with different leading dimensions (parameter
+// packing / unpacking between the exact Keras shapes of the flat bucket and the zero-padded shapes the kernels use)
+__global__ void copy2d_kernel(float* __restrict__ dst, int ldd, const float* __restrict__ src, int lds, int rows, int cols) {
+    const int total = rows * cols;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int r = i / cols, c = i - r * cols;
+        dst[(long long)r * ldd + c] = src[(long long)r * lds + c];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -182,6 +217,34 @@ int ssdseg_act_bwd(ssdseg_ctx* ctx, float* g, int ldg, const float* x, int ldx, 
     SSDSEG_ARG(c > 0 && c % 4 == 0, 7);
     const long long total = (long long)m * (c / 4);
     SSDSEG_LAUNCH(ctx, 12.0 * m * c, 0.0, act_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, g, ldg, x, ldx, (long long)m, c / 4, act);
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+
+int ssdseg_channel_gather(ssdseg_ctx* ctx, const ssdseg_view* in, int ldi, float* out, int ldo, long long m, int c_out,
+                          const int32_t* table, int accumulate) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(in != nullptr && in->x != nullptr && ((in->scale == nullptr) == (in->shift == nullptr)), 2);
+    SSDSEG_ARG(ldi > 0, 3);
+    SSDSEG_ARG(out != nullptr && out != in->x, 4);
+    SSDSEG_ARG(ldo >= c_out, 5);
+    SSDSEG_ARG(m > 0, 6);
+    SSDSEG_ARG(c_out > 0, 7);
+    SSDSEG_ARG(table != nullptr, 8);
+    const long long total = m * c_out;
+    SSDSEG_LAUNCH(ctx, 8.0 * total, 0.0, channel_gather_kernel, dim3(ew_blocks(total)), dim3(256), 0, in->x, in->scale, in->shift, in->act, ldi,
+                  out, ldo, m, c_out, (const int*)table, accumulate);
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+int ssdseg_copy2d(ssdseg_ctx* ctx, float* dst, int ldd, const float* src, int lds, int rows, int cols) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(dst != nullptr, 2);
+    SSDSEG_ARG(src != nullptr, 4);
+    SSDSEG_ARG(rows > 0 && cols > 0 && ldd >= cols && lds >= cols, 6);
+    SSDSEG_LAUNCH(ctx, 8.0 * rows * cols, 0.0, copy2d_kernel, dim3(ew_blocks((long long)rows * cols)), dim3(256), 0, dst, ldd, src, lds, rows, cols);
     SSDSEG_LAUNCH_CHECK();
     return 0;
 }

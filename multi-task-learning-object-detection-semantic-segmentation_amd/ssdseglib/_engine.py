@@ -419,6 +419,67 @@ class ShuffleOp(Op):
         self.e.ctx.call("ssdseg_channel_shuffle", H.view(o.grad), o.ld, g, i.ld, i.m, i.c, self.groups, 1)
 
 
+def pad4(c: int) -> int:
+    """physical channel count of a tensor with c logical channels: the kernels work on 16-byte channel vectors, so a branch
+    of 58 (ShuffleNetV2 '1x') or 122 ('2x') channels lives in a zero-padded 60- / 124-channel tensor"""
+    return (int(c) + 3) // 4 * 4
+
+
+class SplitGatherOp(Op):
+    """channel Split whose parts are not multiples of 4 channels wide (ShuffleNetV2 '1x' / '2x', reference models.py:573):
+    each part is gathered into its own zero-padded dense tensor; backward gathers the parts' gradients back"""
+
+    def __init__(self, eng, inp: Val, outs: List[Store], widths: List[int], name):
+        self.e, self.inp, self.outs, self.name = eng, inp, outs, name
+        cin = inp.store.c
+        self.tf, self.tb = [], []
+        off = 0
+        for st, w in zip(outs, widths):
+            self.tf.append(eng.ctx.array(np.array([off + i if i < w else -1 for i in range(st.c)], np.int32)))
+            self.tb.append(eng.ctx.array(np.array([j - off if off <= j < off + w else -1 for j in range(cin)], np.int32)))
+            off += w
+
+    def fwd(self):
+        i = self.inp.store
+        for st, t in zip(self.outs, self.tf):
+            self.e.ctx.call("ssdseg_channel_gather", self.inp.view(), i.ld, st.buf, st.ld, i.m, st.c, t, 0)
+
+    def bwd(self):
+        i = self.inp.store
+        g, acc = i.grad_slot()
+        for k, (st, t) in enumerate(zip(self.outs, self.tb)):
+            self.e.ctx.call("ssdseg_channel_gather", H.view(st.grad), st.ld, g, i.ld, i.m, i.c, t, 1 if (acc or k > 0) else 0)
+
+
+class TableShuffleOp(Op):
+    """channel shuffle of a concat whose parts carry padding channels: the permutation (reference models.py:497-503) composed
+    with padded -> packed re-indexing, as one table lookup (the lazily fused BN + ReLU of the branches rides along, as in
+    ShuffleOp); backward scatters through the inverse table (padding channels get zero gradient)"""
+
+    def __init__(self, eng, inp: Val, out: Store, groups: int, name):
+        self.e, self.inp, self.out, self.name = eng, inp, out, name
+        parts = inp.store.logical_parts
+        phys_of = [off + i for off, cl in parts for i in range(cl)]
+        c_log = len(phys_of)
+        assert c_log % groups == 0 and pad4(c_log) == out.c
+        fwd = [phys_of[(j % groups) * (c_log // groups) + j // groups] if j < c_log else -1 for j in range(out.c)]
+        inv = [-1] * inp.store.c
+        for j, p in enumerate(fwd):
+            if p >= 0:
+                inv[p] = j
+        self.tf, self.tb = eng.ctx.array(np.array(fwd, np.int32)), eng.ctx.array(np.array(inv, np.int32))
+
+    def fwd(self):
+        i, o = self.inp.store, self.out
+        self.e.ctx.call("ssdseg_channel_gather", self.inp.view(), i.ld, o.buf, o.ld, i.m, o.c, self.tf, 0)
+
+    def bwd(self):
+        i, o = self.inp.store, self.out
+        g, acc = i.grad_slot()
+        assert acc == 0
+        self.e.ctx.call("ssdseg_channel_gather", H.view(o.grad), o.ld, g, i.ld, i.m, i.c, self.tb, 0)
+
+
 class GapOp(Op):
     def __init__(self, eng, inp: Val, out: Store, name):
         self.e, self.inp, self.out, self.name = eng, inp, out, name
@@ -620,8 +681,42 @@ class Engine:
             return None
         return src.view(off, shape)
 
+    @staticmethod
+    def _phys_shape(wname: str, shape) -> Tuple[int, ...]:
+        """shape of a weight as the kernels see it: channel dimensions rounded up to multiples of 4 (only ShuffleNetV2 '1x' /
+        '2x' have any that are not: 58 / 122); taps, the 3 image channels and depth multipliers stay"""
+        s = tuple(int(x) for x in shape)
+        if len(s) == 1:                                     # BatchNormalization vectors, biases
+            return (pad4(s[0]),)
+        if wname == "depthwise_kernel":                     # (kh, kw, c, 1)
+            return (s[0], s[1], pad4(s[2]), s[3])
+        if len(s) == 4 and s[0] == 1 and s[1] == 1:         # pointwise kernels (1, 1, cin, cout)
+            return (1, 1, pad4(s[2]), pad4(s[3]))
+        return s
+
+    def _bucket_view(self, layer, wname, grads=False):
+        which, off, shape = self.P["index"][(id(layer), wname)]
+        return (self.P["grads"] if grads else self.P[which]).view(off, shape)
+
+    def _padded_view(self, layer, wname, kind: str):
+        """zero-padded device copy of a weight (kind "p": parameter / state, refreshed from the bucket before every forward pass;
+        "g": gradient, folded back into the bucket after the backward pass)"""
+        which, off, shape = self.P["index"][(id(layer), wname)]
+        phys = self._phys_shape(wname, shape)
+        reg = self.__dict__.setdefault("_padded", {})
+        key = (id(layer), wname, kind)
+        if key not in reg:
+            dims = [d for d in shape if d != 1] or [1]
+            pdims = [d for d in phys if d != 1] or [1]
+            rows = int(np.prod(dims[:-1])) if len(dims) > 1 else 1
+            reg[key] = dict(buf=self.ctx.zeros(phys), rows=rows, cols=dims[-1], lds=dims[-1], ldd=pdims[-1], layer=layer, wname=wname,
+                            which=which)
+        return reg[key]["buf"]
+
     def param_view(self, layer, wname):
         which, off, shape = self.P["index"][(id(layer), wname)]
+        if self._phys_shape(wname, shape) != tuple(shape):
+            return self._padded_view(layer, wname, "p")
         return self.P[which].view(off, shape)
 
     state_view = param_view
@@ -631,16 +726,32 @@ class Engine:
             return None
         which, off, shape = self.P["index"][(id(layer), wname)]
         assert which == "params"
+        if self._phys_shape(wname, shape) != tuple(shape):
+            return self._padded_view(layer, wname, "g")
         return self.P["grads"].view(off, shape)
+
+    def grad_array(self, layer, wname) -> np.ndarray:
+        """this step's gradient of a weight in its Keras shape (tests)"""
+        return self._bucket_view(layer, wname, grads=True).download()
+
+    def _sync_padded(self, kind: str, to_bucket: bool, which: Optional[str] = None):
+        for (lid, wname, k), r in self.__dict__.get("_padded", {}).items():
+            if k != kind or (which is not None and r["which"] != which):
+                continue
+            bv = self._bucket_view(r["layer"], wname, grads=(kind == "g"))
+            if to_bucket:
+                self.ctx.call("ssdseg_copy2d", bv, r["lds"], r["buf"], r["ldd"], r["rows"], r["cols"])
+            else:
+                self.ctx.call("ssdseg_copy2d", r["buf"], r["ldd"], bv, r["lds"], r["rows"], r["cols"])
 
     def _pull_layer(self, layer):
         self.ctx.sync()
         for wname in layer.weights:
-            layer.weights[wname] = self.param_view(layer, wname).download()
+            layer.weights[wname] = self._bucket_view(layer, wname).download()
 
     def _push_layer(self, layer):
         for wname, arr in layer.weights.items():
-            self.param_view(layer, wname).upload(arr)
+            self._bucket_view(layer, wname).upload(arr)
 
     # ------------------------------------------------------------------ planning helpers
     def _consumers(self) -> Dict[int, List[K.Layer]]:
@@ -661,7 +772,7 @@ class Engine:
                 continue
             off = 0
             for t in l.inbound:
-                c = t.shape[-1]
+                c = pad4(t.shape[-1])
                 cur, ok = t, True
                 # walk back through lazily-fused per-channel layers to whoever writes memory
                 while isinstance(cur.layer, (K.ReLU, K.BatchNormalization)):
@@ -679,8 +790,13 @@ class Engine:
         """(store, wide scale, wide shift) of a channel concat, created on first use"""
         key = id(concat)
         if key not in self.concat_store:
-            n, h, w, c = (self.batch,) + tuple(concat.outputs[0].shape[1:])
+            n, h, w, _ = (self.batch,) + tuple(concat.outputs[0].shape[1:])
+            parts, c = [], 0                       # physical layout: every input at its padded width
+            for t in concat.inbound:
+                parts.append((c, int(t.shape[-1])))
+                c += pad4(t.shape[-1])
             st = Store(self, n, h, w, c, concat.name)
+            st.logical_parts = parts
             st.wide_scale = self.ctx.array(np.ones(c, np.float32))
             st.wide_shift = self.ctx.array(np.zeros(c, np.float32))
             self.concat_store[key] = st
@@ -690,6 +806,7 @@ class Engine:
     def _out_store(self, layer, shape, name=None) -> Tuple[Store, Optional[H.DeviceBuffer], Optional[H.DeviceBuffer]]:
         """fresh dense store for a layer's raw output, or its slice of a concat buffer"""
         n, h, w, c = (self.batch,) + tuple(shape[1:])
+        c = pad4(c)                                # (== c for every model but ShuffleNetV2 '1x' / '2x')
         if id(layer) in self.placement:
             concat, off = self.placement[id(layer)]
             parent = self._concat_parts(concat)
@@ -733,9 +850,6 @@ class Engine:
             self._lower_conv(layer, ins[0], setv)
         elif isinstance(layer, K.DepthwiseConv2D):
             assert layer.strides[0] == layer.strides[1] and layer.dilation_rate[0] == layer.dilation_rate[1]
-            if out_t.shape[-1] % 4 != 0:
-                raise NotImplementedError(f"{layer.name}: {out_t.shape[-1]} channels -- the HIP kernels work on 16-byte channel vectors (multiples of "
-                                          "4 channels); ShuffleNetV2 model_size '1x' / '2x' split into 58 / 122 channels, use '0.5x' or '1.5x'")
             st = self._out_store(layer, out_t.shape)
             op = self._emit(DwOp(self, layer, "depthwise_kernel", self._dense(ins[0], layer.name), st, layer.strides[0], layer.dilation_rate[0]))
             src = layer.inbound[0]
@@ -883,7 +997,7 @@ class Engine:
         off = 0
         copied_nonneg = True
         for t, v in zip(layer.inbound, ins):
-            c = t.shape[-1]
+            c = pad4(t.shape[-1])
             if v.store.parent is parent and v.store.coff == off:
                 acts.add(v.meta.get("materialised_act", v.act))
             else:
@@ -938,6 +1052,17 @@ class Engine:
         elif isinstance(layer, L.Split):
             v = ins[0]
             assert v.scale is None and v.act == ACT_NONE and layer.axis in (-1, 3), f"{layer.name}: only plain channel splits are lowered"
+            if any(t.shape[-1] % 4 != 0 for t in layer.outputs):
+                # parts that are not whole 16-byte channel vectors: gather each into its own zero-padded tensor
+                vd = self._dense(v, layer.name)
+                outs = []
+                for k, t in enumerate(layer.outputs):
+                    st = Store(self, vd.store.n, vd.store.h, vd.store.w, pad4(t.shape[-1]), f"{layer.name}[{k}]")
+                    self.stores.append(st)
+                    outs.append(st)
+                    self.vals[id(t)] = Val(st, nonneg=_nonneg(v))
+                self._emit(SplitGatherOp(self, vd, outs, [int(t.shape[-1]) for t in layer.outputs], layer.name))
+                return
             v.store.split_parent = True
             off = 0
             for t in layer.outputs:
@@ -958,7 +1083,12 @@ class Engine:
             setv(Val(v.store, v.scale, v.shift, v.act, v.bn, shuffle_groups=tgt[2], shuffle_src=v))
         elif v.meta.get("shuffle_permuted"):       # back to (h, w, c): emit the shuffle (models.py:503)
             st = self._out_store(layer, out_t.shape)
-            self._emit(ShuffleOp(self, v.meta["shuffle_src"], st, v.meta["shuffle_groups"], layer.name))
+            src = v.meta["shuffle_src"]
+            parts = getattr(src.store, "logical_parts", None)
+            if parts is not None and any(cl % 4 != 0 for _, cl in parts):
+                self._emit(TableShuffleOp(self, src, st, v.meta["shuffle_groups"], layer.name))
+            else:
+                self._emit(ShuffleOp(self, src, st, v.meta["shuffle_groups"], layer.name))
             setv(Val(st, nonneg=_nonneg(v.meta["shuffle_src"])))
         else:                                      # SSD heads: (B, H, W, boxes*4) -> (B, H*W*boxes, 4), metadata only
             setv(Val(v.store, v.scale, v.shift, v.act, v.bn, reshaped=tgt, **{k: x for k, x in v.meta.items() if k != "reshaped"}))
@@ -976,8 +1106,11 @@ class Engine:
             self.input_store.buf.upload(a)
 
     def forward(self):
+        self._sync_padded("p", to_bucket=False)          # padded copies of the weights <- bucket (no-op for most models)
         for op in self.ops:
             op.fwd()
+        if self.training:
+            self._sync_padded("p", to_bucket=True, which="state")   # moving statistics of padded BatchNorms -> bucket
 
     def backward(self):
         for s in self.stores:
@@ -991,6 +1124,7 @@ class Engine:
         for s in self.stores:
             s._materialise_pending()
         self.ctx.join()     # weight-gradient kernels on the side stream: done before anyone (optimizer, all-reduce) reads them
+        self._sync_padded("g", to_bucket=True)   # gradients of zero-padded weights -> their Keras-shaped slots of the bucket
 
     def seed_output_grad(self, index: int, g):
         """inject dL/d(output[index]) (bench config 2 / tests): output values are the ACTIVATED tensors"""
@@ -1014,6 +1148,7 @@ class Engine:
         for s in self.stores:
             s._materialise_pending()
         self.ctx.join()
+        self._sync_padded("g", to_bucket=True)
 
     def output(self, index: int) -> np.ndarray:
         """activated value of output `index` as a NumPy array (N, H, W, C) -- for tests / predict"""
@@ -1026,6 +1161,8 @@ class Engine:
             self.ctx.call("ssdseg_bn_apply", v.view(), s.ld, None, 0, tmp, s.c, s.m, s.c)
             arr = tmp.download().reshape(s.n, s.h, s.w, s.c)
         shp = self.model.outputs[index].shape
+        if arr.shape[-1] != shp[-1] and arr.ndim == 4 and len(shp) == 4:
+            arr = np.ascontiguousarray(arr[..., :shp[-1]])      # zero-padded channels of an odd-width tensor
         return arr.reshape((s.n,) + tuple(shp[1:]))
 
     # ------------------------------------------------------------------ training step (Keras train_step stand-in)

@@ -32,7 +32,7 @@ def device_relu_masks(eng, model):
         flat = s.buf.download().ravel()       # a concat slice starts `coff` floats into its parent: index rows explicitly
         y = flat[np.arange(s.m)[:, None] * s.ld + np.arange(s.c)[None, :]].astype(np.float64)
         z = y if v.scale is None else y * v.scale.download().astype(np.float64) + v.shift.download().astype(np.float64)
-        z = z.astype(np.float32).reshape(s.n, s.h, s.w, s.c)
+        z = z.astype(np.float32).reshape(s.n, s.h, s.w, s.c)[..., :l.outputs[0].shape[-1]]   # (drop zero-padded channels: ShuffleNetV2 '1x')
         masks[l.name] = O.act_mask(z, v.act)
     return masks
 
