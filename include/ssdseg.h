@@ -162,11 +162,14 @@ int ssdseg_dwconv_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, co
                       float* dw, int n, int h, int wdt, int c, int stride, int dilation, int accumulate);
 /* The same plus the BatchNormalization backward of the layer that FEEDS this conv (in = act(scale*x + shift) is a BN view,
  * models.py:66-67 -> :88): the kernel that writes dx also reduces sum(mask*dx) and sum(mask*dx*xhat) over it, so the
- * 6x-wide expand tensors are not re-read by ssdseg_bn_bwd_reduce.  Only valid when this conv is the ONLY consumer of the
- * BN output (dx is overwritten, never accumulated).  Outputs (dgamma, dbeta may be NULL): as ssdseg_bn_bwd_reduce. */
+ * 6x-wide expand tensors are not re-read by ssdseg_bn_bwd_reduce.  Valid when this conv is the only consumer of the BN
+ * output (accumulate = 0) or the LAST of several to contribute (accumulate != 0: dx already holds the other consumers'
+ * gradients -- a backbone tap that also feeds the heads -- and the sums are taken over the completed dx).
+ * Outputs (dgamma, dbeta may be NULL): as ssdseg_bn_bwd_reduce. */
 int ssdseg_dwconv_bwd_bn(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, const ssdseg_gview* dy, float* dx,
-                         float* dw, int n, int h, int wdt, int c, int stride, int dilation, const float* in_mean,
-                         const float* in_invstd, float* in_dgamma, float* in_dbeta, float* in_k1, float* in_k0);
+                         float* dw, int n, int h, int wdt, int c, int stride, int dilation, int accumulate,
+                         const float* in_mean, const float* in_invstd, float* in_dgamma, float* in_dbeta, float* in_k1,
+                         float* in_k0);
 
 /* ---------------------------------------------------------------- K5: pointwise 1x1 conv == GEMM [m,k] x [k,n]
  * Conv2D 1x1 / pointwise half of SeparableConv2D (models.py:65,110,527,...; blocks.py:28,58,70,109).

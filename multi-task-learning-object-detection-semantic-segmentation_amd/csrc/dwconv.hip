@@ -399,7 +399,7 @@ int dw_bwd_impl(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, const ss
         MarchGeom mg;
         const MarchLaunch ml = march_geometry(n, h, wdt, c, &mg, dilation);
         const int nparts = (int)ml.grid.x;
-        const bool fuse = bn != nullptr && !accumulate && dilation == 1;
+        const bool fuse = bn != nullptr && dilation == 1 && dx != nullptr;   // (with accumulate: this conv is the LAST writer of dx)
         void* ws;
         int rc = ssdseg_workspace(ctx, (size_t)nparts * 11 * c * sizeof(float), &ws);
         if (rc) return rc;
@@ -411,7 +411,9 @@ int dw_bwd_impl(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, const ss
                   fuse ? bn->mean : (const float*)nullptr, fuse ? bn->invstd : (const float*)nullptr, fuse ? bnpart : (float*)nullptr)
         if (dilation > 1 && accumulate) DW_BWD_MARCH(false, false, true, true);
         else if (dilation > 1) DW_BWD_MARCH(false, false, false, true);
-        else if (fuse && wfull) DW_BWD_MARCH(true, true, false, false);        // (the fused BN sums imply a sole consumer: never accumulating)
+        else if (fuse && wfull && accumulate) DW_BWD_MARCH(true, true, true, false);
+        else if (fuse && accumulate) DW_BWD_MARCH(true, false, true, false);
+        else if (fuse && wfull) DW_BWD_MARCH(true, true, false, false);
         else if (fuse) DW_BWD_MARCH(true, false, false, false);
         else if (wfull && accumulate) DW_BWD_MARCH(false, true, true, false);
         else if (wfull) DW_BWD_MARCH(false, true, false, false);
@@ -430,7 +432,7 @@ int dw_bwd_impl(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, const ss
         March2Geom mg;
         const MarchLaunch ml = march2_geometry(n, h, wdt, c, g.ho, g.wo, &mg);
         const int nparts = (int)ml.grid.x;
-        const bool fuse = bn != nullptr && !accumulate;
+        const bool fuse = bn != nullptr && dx != nullptr;
         void* ws;
         int rc = ssdseg_workspace(ctx, (size_t)nparts * 11 * c * sizeof(float), &ws);
         if (rc) return rc;
@@ -447,7 +449,8 @@ int dw_bwd_impl(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, const ss
         else if (g.pl == 0) DW_BWD_MARCH2(BN_, 1, 0, AC_);    \
         else DW_BWD_MARCH2(BN_, 1, 1, AC_);                   \
     } while (0)
-        if (fuse) DW_BWD_MARCH2_P(true, false);
+        if (fuse && accumulate) DW_BWD_MARCH2_P(true, true);
+        else if (fuse) DW_BWD_MARCH2_P(true, false);
         else if (accumulate && dx != nullptr) DW_BWD_MARCH2_P(false, true);
         else DW_BWD_MARCH2_P(false, false);
 #undef DW_BWD_MARCH2_P
@@ -571,7 +574,7 @@ int ssdseg_dwconv_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, co
 }
 
 int ssdseg_dwconv_bwd_bn(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, const ssdseg_gview* dy, float* dx, float* dw, int n,
-                         int h, int wdt, int c, int stride, int dilation, const float* in_mean, const float* in_invstd,
+                         int h, int wdt, int c, int stride, int dilation, int accumulate, const float* in_mean, const float* in_invstd,
                          float* in_dgamma, float* in_dbeta, float* in_k1, float* in_k0) {
     SSDSEG_ARG(ctx != nullptr, 1);
     SSDSEG_ARG(in != nullptr && in->x != nullptr && in->scale != nullptr && in->shift != nullptr, 2);
@@ -584,11 +587,11 @@ int ssdseg_dwconv_bwd_bn(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w,
     SSDSEG_ARG(c > 0 && c % 4 == 0, 10);
     SSDSEG_ARG(stride == 1 || stride == 2, 11);
     SSDSEG_ARG(dilation >= 1 && (dilation == 1 || stride == 1), 12);
-    SSDSEG_ARG(in_mean != nullptr && in_invstd != nullptr, 13);
-    SSDSEG_ARG(in_k1 != nullptr && in_k0 != nullptr, 17);
+    SSDSEG_ARG(in_mean != nullptr && in_invstd != nullptr, 14);
+    SSDSEG_ARG(in_k1 != nullptr && in_k0 != nullptr, 18);
     const BnFuse bn{in_mean, in_invstd, in_dgamma, in_dbeta, in_k1, in_k0};
     bool done = false;
-    int rc = dw_bwd_impl(ctx, in, w, dy, dx, dw, n, h, wdt, c, stride, dilation, 0, &bn, &done);
+    int rc = dw_bwd_impl(ctx, in, w, dy, dx, dw, n, h, wdt, c, stride, dilation, accumulate, &bn, &done);
     if (rc || done) return rc;
     // shapes without a fused kernel: the same reduction as a separate pass over (dx, x)
     return ssdseg_bn_bwd_reduce(ctx, dx, c, in->x, c, n * h * wdt, c, in->scale, in->shift, in_mean, in_invstd, in->act, in_dgamma, in_dbeta,

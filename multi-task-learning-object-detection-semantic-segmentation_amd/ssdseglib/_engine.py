@@ -217,16 +217,18 @@ class DwOp(Op):
         self.e.ctx.call("ssdseg_dwconv_fwd", self.inp.view(), self.w, self.out.buf, s.n, s.h, s.w, s.c, self.stride, self.dilation,
                         self.out.stats)
 
-    fuse_input_bn = False   # set by the lowering when this conv is the only consumer of a BatchNorm(+ReLU) output
+    # set by the lowering when this conv is the only consumer of a BatchNorm(+ReLU) output, or the FIRST of several in layer
+    # order -- i.e. the last one to contribute to that gradient in the backward pass (a backbone tap that also feeds the heads)
+    fuse_input_bn = False
 
     def bwd(self):
         s = self.inp.store
         dx, acc = (s.grad_slot() if s.need_grad else (None, 0))
         b = self.inp.bn
-        if self.fuse_input_bn and b is not None and dx is not None and acc == 0:
-            # the kernel that writes dx also reduces the producer BN's (dgamma, dbeta, k1, k0): no second pass over the 6x-wide tensor
+        if self.fuse_input_bn and b is not None and dx is not None:
+            # the kernel that completes dx also reduces the producer BN's (dgamma, dbeta, k1, k0): no second pass over the wide tensor
             self.e.ctx.call("ssdseg_dwconv_bwd_bn", self.inp.view(), self.w, self.out_val.gview(), dx, self.dw, s.n, s.h, s.w, s.c,
-                            self.stride, self.dilation, b.mean, b.invstd, b.dgamma, b.dbeta, b.k1, b.k0)
+                            self.stride, self.dilation, acc, b.mean, b.invstd, b.dgamma, b.dbeta, b.k1, b.k0)
             b.bwd_done = True
             return
         self.e.ctx.call("ssdseg_dwconv_bwd", self.inp.view(), self.w, self.out_val.gview(), dx, self.dw, s.n, s.h, s.w, s.c, self.stride,
@@ -853,8 +855,9 @@ class Engine:
             st = self._out_store(layer, out_t.shape)
             op = self._emit(DwOp(self, layer, "depthwise_kernel", self._dense(ins[0], layer.name), st, layer.strides[0], layer.dilation_rate[0]))
             src = layer.inbound[0]
-            op.fuse_input_bn = (op.inp is ins[0] and ins[0].bn is not None and len(self.cons.get(id(src), [])) == 1
-                                and id(src) not in {id(t) for t in self.model.outputs})
+            cons = self.cons.get(id(src), [])
+            op.fuse_input_bn = (op.inp is ins[0] and ins[0].bn is not None and ins[0].store.parent is None and bool(cons) and cons[0] is layer
+                                and layer.dilation_rate[0] == 1)
             op.out_val = Val(st)
             setv(op.out_val)
             st.producer = op

@@ -77,7 +77,7 @@ _SIGNATURES = {
     "ssdseg_dwconv_parts": [_i, _i, _i, _i, _i, _i, _ip],
     "ssdseg_dwconv_fwd": [_vp, _VP, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "ssdseg_dwconv_bwd": [_vp, _VP, _vp, _GP, _vp, _vp, _i, _i, _i, _i, _i, _i, _i],
-    "ssdseg_dwconv_bwd_bn": [_vp, _VP, _vp, _GP, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ssdseg_dwconv_bwd_bn": [_vp, _VP, _vp, _GP, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "ssdseg_pwconv_parts": [_i, _i, _ip],
     "ssdseg_pwconv_fwd": [_vp, _VP, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "ssdseg_pwconv_bwd_data": [_vp, _GP, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i],

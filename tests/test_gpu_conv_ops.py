@@ -109,7 +109,7 @@ def test_dwconv_fwd_bwd(ctx, rng, kernel_family, n, h, w, c, s, d, act):
     mean = x.mean(axis=(0, 1, 2), dtype=np.float64).astype(np.float32)
     invstd = (1.0 / np.sqrt(x.var(axis=(0, 1, 2), dtype=np.float64) + 1e-3)).astype(np.float32)
     outs = [ctx.empty(c) for _ in range(4)]
-    ctx.call("ssdseg_dwconv_bwd_bn", H.view(dx_, dsc, dsh, act), dw_, gv, ddx, ddw, n, h, w, c, s, d, ctx.array(mean), ctx.array(invstd), *outs)
+    ctx.call("ssdseg_dwconv_bwd_bn", H.view(dx_, dsc, dsh, act), dw_, gv, ddx, ddw, n, h, w, c, s, d, 0, ctx.array(mean), ctx.array(invstd), *outs)
     assert rel_err(ddx.download(), dx_ref) < 2e-5
     assert rel_err(ddw.download(), dw_ref) < 1e-4
     z = x.astype(np.float64) * sc + sh
@@ -124,6 +124,15 @@ def test_dwconv_fwd_bwd(ctx, rng, kernel_family, n, h, w, c, s, d, act):
     k0_ref = sc.astype(np.float64) * (dgamma * invstd * mean - dbeta) / cnt
     assert np.abs(outs[2].download() - k1_ref).max() < 1e-4 * max(np.abs(k1_ref).max(), 1e-9)
     assert np.abs(outs[3].download() - k0_ref).max() < 1e-4 * max(np.abs(k0_ref).max(), 1e-9)
+    # last of several consumers: dx already holds the others' gradients; the BN sums are over the completed dx
+    ddx.upload(base)
+    ctx.call("ssdseg_dwconv_bwd_bn", H.view(dx_, dsc, dsh, act), dw_, gv, ddx, ddw, n, h, w, c, s, d, 1, ctx.array(mean), ctx.array(invstd), *outs)
+    tot = dx_ref.astype(np.float64) + base
+    assert rel_err(ddx.download(), tot) < 2e-5
+    mg = tot * O.act_mask(z, act)
+    dbeta, dgamma = mg.sum(axis=(0, 1, 2)), (mg * xhat).sum(axis=(0, 1, 2))
+    tol = 1e-4 * max(np.abs(dgamma).max(), np.abs(dbeta).max(), 1e-6)
+    assert np.abs(outs[0].download() - dgamma).max() < tol and np.abs(outs[1].download() - dbeta).max() < tol
 
 
 PW_CASES = [
