@@ -1084,7 +1084,11 @@ int wgrad_run(ssdseg_ctx* ctx, WGradArgs a, float* dw) {
     // the 4-way row-split shape stages 64 x (32*wn) of (g, y) per step: beyond 3 column tiles it needs > 256 VGPRs (1 wave/SIMD)
     if (wi == 1 && wn > 3) wn = 3;
     const int jtiles = cdiv(n, 32 * wn);
-    static const long long bpc = getenv("SSDSEG_WGRAD_BPC") ? atoll(getenv("SSDSEG_WGRAD_BPC")) : 2;   // target blocks per CU (2 measured ~1 % ahead of 4-8: fewer, longer splits, half the partial slabs)
+    // target blocks per CU: the long-M (HBM-bound) layers want more, shorter splits in flight; the short-M ones fewer, longer
+    // splits (half the partial slabs, prologue / epilogue amortised over more steps)
+    static const long long bpc_long = getenv("SSDSEG_WGRAD_BPC_LONG") ? atoll(getenv("SSDSEG_WGRAD_BPC_LONG")) : 4;
+    static const long long bpc_short = getenv("SSDSEG_WGRAD_BPC") ? atoll(getenv("SSDSEG_WGRAD_BPC")) : 2;
+    const long long bpc = m >= ROWA_OCC_ROWS ? bpc_long : bpc_short;
     long long want = (bpc * ctx->num_cus + (long long)itiles * jtiles - 1) / ((long long)itiles * jtiles);
     long long splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
     if (splits > 65535) splits = 65535;
