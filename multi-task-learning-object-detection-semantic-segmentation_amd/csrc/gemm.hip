@@ -99,6 +99,7 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 // chip twice anyway) and ran 10-25 % SLOWER with the tight allocation.  Dispatch: rows >= ROWA_OCC_ROWS.
 constexpr int rowa_min_waves(int WN, int MODE, int NT) { return NT > 0 ? 2 : (WN >= 2 ? 2 : (MODE == 0 ? 4 : 3)); }
 constexpr int ROWA_OCC_ROWS = 150000;
+inline long long occ_rows() { static const long long v = getenv("SSDSEG_OCC_ROWS") ? atoll(getenv("SSDSEG_OCC_ROWS")) : ROWA_OCC_ROWS; return v; }
 template <int WN, int MODE, int LD, int NT = 0, int EP = 0, int OCC = 0>
 __global__ void __launch_bounds__(256, OCC ? rowa_min_waves(WN, MODE, NT) : 1) gemm_rowA_kernel(RowAArgs p) {
     constexpr bool CONV = LD == 1, STEM = LD == 2, FUSEW = NT > 0, F4 = EP >= 1, BNE = EP == 2;
@@ -960,7 +961,7 @@ int launch_rowA(ssdseg_ctx* ctx, const RowAArgs& a0) {
     const double streamed = (MODE == 1 && a.cs != nullptr) ? 2.0 : 1.0;
     const double cost_bytes = 4.0 * (streamed * a.I * a.R + (double)a.I * a.J + (double)a.R * a.J);
     const double cost_flops = 2.0 * a.I * a.R * a.J;
-    const bool occ = a.I >= ROWA_OCC_ROWS;
+    const bool occ = a.I >= occ_rows();
     char kbuf[64];
     // Measured per layer on MI355X (profiles/r01_wres_vs_general_per_layer.txt): the resident kernel wins when every wave
     // streams several row tiles (>= ~500k rows: the 240x320 and 120x160 stages at batch 32) and loses 10-30 % below that,
@@ -1342,7 +1343,7 @@ int ssdseg_pwconv_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssd
         }
         return ssdseg_colsum(ctx, a.wpart, gy, (long long)k * n, dw);
     }
-    const bool occ = a.I >= ROWA_OCC_ROWS;
+    const bool occ = a.I >= occ_rows();
     char fbuf[64];
     snprintf(fbuf, sizeof(fbuf), "gemm_rowA_kernel<1, 1, 0, %d, 0, %d>", nt > 6 ? 6 : nt, (int)occ);   // NT > 0: fused dW
     const char* kname = ctx->timing ? ssdseg_intern(fbuf) : "";
@@ -1433,7 +1434,7 @@ int ssdseg_pwconv_bwd_bn(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const 
     if (cs > lds) lds = cs;
     const double cost_bytes = 4.0 * ((dy->scale != nullptr ? 2.0 : 1.0) * m * n + 2.0 * m * k + (double)k * n);
     const double cost_flops = 2.0 * m * k * n;
-    const bool occ = m >= ROWA_OCC_ROWS;
+    const bool occ = m >= occ_rows();
     char kbuf[64];
     snprintf(kbuf, sizeof(kbuf), "gemm_rowA_kernel<%d, 1, 0, 0, 2, %d>", wn, (int)occ);
     const char* kname = ctx->timing ? ssdseg_intern(kbuf) : "";
