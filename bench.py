@@ -2,19 +2,22 @@
 """bench.py -- images/sec of the ssdseglib hot path on MI355X (contract: task statement / DESIGN.md "Measurement").
 
 Workloads (BASELINE.json `configs`):
-  backbone (default, configs[1], the configuration the metric is quoted on at N=1):
-      MobileNetV2 backbone blocks 0..16 (reference models.py:169-215) forward + backward at batch 32/GPU, 480x640x3,
-      fp32, synthetic upstream gradients on the three tensors the heads tap (`backbone-block16-project-batchnorm`,
-      `backbone-block3-expand-relu6`, `backbone-block13-expand-relu6`), gradient all-reduce (N>1), Adam.
-  full (configs[2]/[3]): the whole MobileNetV2-SSDLite-DeepLabV3+ train step: anchor encode -> forward -> 3 losses
-      (weighted CE, confidence with hard-negative mining, localization) -> backward -> all-reduce -> Adam.
+  full (default, configs[2]; configs[3] when launched on N GPUs): the whole MobileNetV2-SSDLite-DeepLabV3+ train step at
+      batch 32/GPU, 480x640x3, fp32: anchor encode -> forward -> 3 losses (weighted CE, confidence with hard-negative
+      mining, localization) -> backward -> all-reduce (N > 1) -> Adam.  The largest single-GPU configuration of BASELINE.json
+      and the one its metric ("images/sec fwd+bwd at 1/2/4/8 GPUs") is quoted on.
+  backbone (configs[1]): MobileNetV2 backbone blocks 0..16 (reference models.py:169-215) forward + backward, synthetic
+      upstream gradients on the three tensors the heads tap, all-reduce (N > 1), Adam.
+  shufflenet (configs[4], per-GPU share): the full train step on the ShuffleNetV2-1x variant.
 
-One process per GPU (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`); torch is plumbing only
-(RCCL process group + the gradient-bucket tensor); every kernel is ours (libssdseg_hip.so).  Weak scaling: each rank
-owns a 32-image shard, one collective per step.
+One process per GPU (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` only provides RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_*): the collective is RCCL behind our C-ABI (ssdseg_allreduce_grads), the 128-byte RCCL id
+travels through a file (ssdseglib/_parallel.py) -- no torch in this file or in the product path.  Weak scaling: each rank owns a
+32-image shard, one collective per step (gradients summed, BatchNorm moving statistics averaged).
 
-Rank 0 prints ONE JSON line with `roofline` (dominant kernel symbol; durations from HIP events recorded around every
-launch of the timed region, on the launch stream, inside the C library) and `cpu_baseline` (NumPy oracle, bounded sample).
+Rank 0 prints ONE JSON line with `roofline` (dominant kernel symbol; durations from HIP events recorded around every launch of
+that kernel in the timed region, on the launch stream, inside the C library; bytes / flops per SURVEY.md 8(d)) and
+`cpu_baseline` (NumPy oracle of the same step, bounded sample).
 """
 import argparse
 import ctypes as C
@@ -120,10 +123,10 @@ class BackboneStep:
     workload = ("BASELINE.json configs[1]: MobileNetV2 backbone-only fwd+bwd(+all-reduce)+Adam, batch 32/GPU, 480x640x3, synthetic "
                 "upstream gradients on the 3 head taps")
 
-    def __init__(self, ctx, batch, rank, reducer, grad_bucket=None):
+    def __init__(self, ctx, batch, rank, reducer):
         from ssdseglib import _engine as E
         self.model = build_backbone_model()
-        self.eng = E.Engine(self.model, batch, training=True, ctx=ctx, grad_bucket=grad_bucket)
+        self.eng = E.Engine(self.model, batch, training=True, ctx=ctx)
         self.reducer = reducer
         self.eng.set_input(synthetic_images(batch, 1993 + rank))
         rng = np.random.default_rng(7 + rank)
@@ -147,10 +150,10 @@ class FullStep:
 
     kind = "mobilenetv2"
 
-    def __init__(self, ctx, batch, rank, reducer, grad_bucket=None):
+    def __init__(self, ctx, batch, rank, reducer):
         from ssdseglib import _engine as E
         boxes, self.model = build_full_model(self.kind)
-        self.eng = E.Engine(self.model, batch, training=True, ctx=ctx, grad_bucket=grad_bucket)
+        self.eng = E.Engine(self.model, batch, training=True, ctx=ctx)
         self.eng.configure_losses(self.model._compiled["loss"], self.model._compiled["loss_weights"])
         self.reducer, self.ctx, self.batch = reducer, ctx, batch
         self.eng.set_input(synthetic_images(batch, 1993 + rank))
@@ -310,7 +313,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
-    ap.add_argument("--workload", default="backbone", choices=["backbone", "full", "shufflenet"])
+    ap.add_argument("--workload", default="full", choices=["backbone", "full", "shufflenet"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events in the timed region")
     args = ap.parse_args()
@@ -323,38 +326,23 @@ def main():
               f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...`", file=sys.stderr)
         sys.exit(2)
 
-    dist = None
-    reducer = None
-    grad_bucket = None
-    if world > 1:
-        import torch
-        # rehearsal switches (one-GPU box): SSDSEG_BENCH_BACKEND=gloo SSDSEG_BENCH_DEVICE=0 runs all ranks on one card over gloo
-        backend = os.environ.get("SSDSEG_BENCH_BACKEND", "nccl")
-        device = int(os.environ.get("SSDSEG_BENCH_DEVICE", local_rank))
-        torch.cuda.set_device(device)
-        dist = P.init_process_group(backend=backend, device_index=device)
-        # our kernels and the RCCL collective are ordered on ONE torch stream (borrowed, not owned, by the ctx): a non-blocking
-        # high-priority stream made current, so the collective's stream-ordering hooks and our launches agree on it
-        main_stream = torch.cuda.Stream(device=device, priority=-1)
-        torch.cuda.set_stream(main_stream)
-        local_rank = device
-        ctx = H.Context(device, stream=main_stream.cuda_stream)
-        model_for_count = (build_backbone_model() if args.workload == "backbone" else
-                           build_full_model("shufflenetv2" if args.workload == "shufflenet" else "mobilenetv2")[1])
-        n_params = sum(int(l.weights[w].size) for l in model_for_count.layers for w in l.trainable_names)
-        bucket_t = torch.zeros(n_params, dtype=torch.float32, device=f"cuda:{local_rank}")
-        grad_bucket = ctx.borrow(bucket_t.data_ptr(), (n_params,), np.float32, owner=bucket_t)
-        reducer = P.GradientAllReduce(bucket_t)
-    else:
-        ctx = H.Context(local_rank)
+    # rehearsal switch (one-GPU box): SSDSEG_BENCH_DEVICE=0 puts every rank on one card -- then SSDSEG_COMM=host is needed too,
+    # RCCL refuses two ranks on one device
+    device = int(os.environ.get("SSDSEG_BENCH_DEVICE", local_rank))
+    ctx = H.Context(device)
+    comm = P.init_comm(ctx)                      # None for a single process; RCCL communicator otherwise
 
-    step = STEPS[args.workload](ctx, args.batch, rank, reducer, grad_bucket)
+    step = STEPS[args.workload](ctx, args.batch, rank, None)
+    if comm is not None:
+        step.reducer = P.GradientAllReduce(comm, step.eng)
+        comm.broadcast(step.eng.P["params"], 0)  # replicas start identical whatever the seeds did
+        if step.eng.P["n_st"]:
+            comm.broadcast(step.eng.P["state"], 0)
 
     def barrier():
         ctx.sync()
-        if dist is not None:
-            torch.cuda.synchronize()
-            dist.barrier()
+        if comm is not None:
+            comm.barrier()
 
     for _ in range(args.warmup):
         step()
@@ -380,8 +368,6 @@ def main():
     for _ in range(args.steps):
         step()
     ctx.sync()
-    if dist is not None:
-        torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
     report = ctx.timing_report() if not args.no_kernel_timing else {}
@@ -401,10 +387,8 @@ def main():
         ctx.side_enable(True)
     ctx.timing(False)
 
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    if comm is not None:
+        elapsed = comm.max(elapsed)              # the slowest rank defines the step
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -414,24 +398,38 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": step.workload, "global_batch": args.batch * world, "per_gpu_batch": args.batch,
-                       "parallelism": f"dp{world}", "device": ctx.device_name()},
+                       "parallelism": f"dp{world}", "collective": (comm.transport if comm is not None else None), "device": ctx.device_name()},
         }
         if report:
             total_ms = sum(v["ms"] for v in survey.values())           # all kernels of the survey step
             name, dom = dominant, report[dominant]                       # dominant kernel: timed-region launches only
-            avg_ms = dom["ms"] / dom["count"]
-            gbs = dom["bytes"] / dom["count"] / (avg_ms * 1e-3) / 1e9
-            tfs = dom["flops"] / dom["count"] / (avg_ms * 1e-3) / 1e12
+
+            def roof(d):
+                """achieved = algorithmic bytes (or flops) per launch / average launch duration; the bound is whichever
+                roof the kernel sits closer to"""
+                avg_ms = d["ms"] / d["count"]
+                gbs = d["bytes"] / d["count"] / (avg_ms * 1e-3) / 1e9
+                tfs = d["flops"] / d["count"] / (avg_ms * 1e-3) / 1e12
+                return avg_ms, gbs, tfs
+
+            avg_ms, gbs, tfs = roof(dom)
             hbm_frac, mfma_frac = gbs / HBM_PEAK_GBS, tfs / MFMA_F32_PEAK_TFLOPS
             bound = "mfma" if mfma_frac > hbm_frac else "hbm"
             traffic, traffic_src = pmc_traffic(name, args.workload, args.batch)
+            alg_bytes, view_bytes = dom["bytes"] / dom["count"], dom.get("view_bytes", 0.0) / dom["count"]
             out["roofline"] = {
                 "kernel": name, "bound": bound,
                 "achieved": round(tfs if bound == "mfma" else gbs, 2), "peak": MFMA_F32_PEAK_TFLOPS if bound == "mfma" else HBM_PEAK_GBS,
                 "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": round(mfma_frac if bound == "mfma" else hbm_frac, 4),
                 "traffic": traffic, "traffic_source": traffic_src, "launches": dom["count"], "avg_launch_ms": round(avg_ms, 4),
                 "share_of_kernel_time": round(survey[dominant]["ms"] / total_ms, 4),
-                "algorithmic_bytes_per_launch": dom["bytes"] / dom["count"], "flops_per_launch": dom["flops"] / dom["count"],
+                # SURVEY.md 8(d): depthwise bwd 4(2X+Y+18C), pointwise read X + write Y + W, dense 3x3 X + Y + W (never the im2col operand)
+                "algorithmic_bytes_per_launch": alg_bytes, "flops_per_launch": dom["flops"] / dom["count"],
+                # what this design reads ON TOP of 8(d)'s ideal: the raw forward output y next to g wherever dY is a BatchNorm-backward
+                # gradient view (reported, never counted in `achieved`)
+                "gradient_view_second_tensor_bytes_per_launch": view_bytes,
+                "hbm_GBps_incl_view_bytes": round((alg_bytes + view_bytes) / (avg_ms * 1e-3) / 1e9, 1),
+                "traffic_over_algorithmic": round(traffic / alg_bytes, 3) if traffic else None,
             }
             ach = achievable_ceiling(bound)
             if ach is not None:
@@ -439,28 +437,37 @@ def main():
                 out["roofline"]["achievable_ceiling"] = ach
             if dominant in isolated and isolated[dominant]["count"] > 0:
                 iso = isolated[dominant]
-                iso_ms = iso["ms"] / iso["count"]
-                igbs = iso["bytes"] / iso["count"] / (iso_ms * 1e-3) / 1e9
-                itfs = iso["flops"] / iso["count"] / (iso_ms * 1e-3) / 1e12
+                iso_ms, igbs, itfs = roof(iso)
                 out["roofline_isolated"] = {
                     "kernel": name, "note": "same kernel, 3 extra steps with the side stream disabled (no co-running weight-gradient kernel)",
                     "achieved": round(itfs if bound == "mfma" else igbs, 2), "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
                     "frac": round((itfs / MFMA_F32_PEAK_TFLOPS) if bound == "mfma" else (igbs / HBM_PEAK_GBS), 4),
                     "launches": iso["count"], "avg_launch_ms": round(iso_ms, 4)}
-            top = sorted(survey.items(), key=lambda kv: -kv[1]["ms"])[:14]
+            # the north-star's two roofline targets, each on the heaviest kernel of its class in the survey step (side stream off)
+            def heaviest(pred):
+                c = [(k, v) for k, v in survey.items() if pred(k) and v["ms"] > 0]
+                return max(c, key=lambda kv: kv[1]["ms"]) if c else None
+            dwk = heaviest(lambda k: k.lstrip("(").startswith("dw_bwd"))
+            if dwk is not None:
+                a, g, _ = roof(dwk[1])
+                out["roofline_depthwise_bwd"] = {"kernel": dwk[0], "bound": "hbm", "achieved": round(g, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                 "frac": round(g / HBM_PEAK_GBS, 4), "launches": dwk[1]["count"], "avg_launch_ms": round(a, 4),
+                                                 "note": "survey step (isolated); bytes = 4(2X+Y+18C) per SURVEY.md 8(d)"}
+            top = sorted(survey.items(), key=lambda kv: -kv[1]["ms"])[:16]
             out["kernels_survey_step"] = [
                 {"kernel": k, "launches": v["count"], "ms_per_step": round(v["ms"], 4),
                  "GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0.0,
                  "TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0.0} for k, v in top]
             out["kernel_ms_per_step"] = round(total_ms, 3)
-        if world == 1:
+        if world == 1 and args.workload != "backbone":
             out["nms_boxes_per_sec"] = nms_boxes_per_sec(ctx, args.batch)   # the metric's second figure (outside the timed region)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, 12 if args.workload == "backbone" else 3)   # ~10-20 s of host work
+            out["cpu_baseline"] = cpu_baseline(args.workload, 12 if args.workload == "backbone" else 3)   # ~10-30 s of host work
         print(json.dumps(out), flush=True)
 
-    if dist is not None:
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
 
 
 if __name__ == "__main__":

@@ -78,14 +78,13 @@ typedef struct {
 const char* ssdseg_last_error(void);
 int ssdseg_version(void);
 int ssdseg_device_count(int* count_host);
-/* stream == NULL: the ctx creates (and owns) a non-blocking stream; otherwise it borrows the caller's
- * hipStream_t (e.g. torch.cuda.current_stream().cuda_stream when RCCL plumbing is torch.distributed). */
+/* stream == NULL: the ctx creates (and owns) a non-blocking stream; otherwise it borrows the caller's hipStream_t. */
 int ssdseg_ctx_create(int device, void* stream, ssdseg_ctx** out_host);
 int ssdseg_ctx_destroy(ssdseg_ctx* ctx);
 int ssdseg_ctx_sync(ssdseg_ctx* ctx);
 /* Weight-gradient kernels run on an internal side stream, concurrently with the rest of the backward pass.  Every entry point
- * that synchronises, copies, records an event or runs the optimizer joins it implicitly; a caller that hands the gradient
- * buffers to ANOTHER library on the ctx stream (the RCCL all-reduce of torch.distributed) calls this first. */
+ * that synchronises, copies, records an event, all-reduces or runs the optimizer joins it implicitly; a caller that hands the
+ * gradient buffers to ANOTHER library on the ctx stream calls this first. */
 int ssdseg_ctx_join(ssdseg_ctx* ctx);
 /* on != 0: the launches that follow go to the side stream (after everything queued so far); on == 0: back to the ctx stream.
  * For callers that issue a weight-gradient entry point themselves (ssdseg_pwconv_bwd does this internally). */
@@ -114,7 +113,6 @@ int ssdseg_timing_reset(ssdseg_ctx* ctx);
 /* bracket only launches of one kernel symbol (low overhead inside a timed region); NULL or "" = every kernel */
 int ssdseg_timing_filter(ssdseg_ctx* ctx, const char* kernel);
 int ssdseg_timing_report(ssdseg_ctx* ctx, char* buf_host, size_t buf_len);
-/* hipGraph capture of a sequence of launches on the ctx stream (launch-bound inner loops) */
 /* Overlapped uploads (new: the reference feeds tf.data batches, NB03#cell8,16).  Pinned host memory and a copy stream
  * per ctx: ssdseg_upload_async enqueues host -> device on the copy stream; ssdseg_upload_fence marks a point on the ctx stream
  * (typically right after the kernels / copies that read a staging buffer) and after_fence != 0 keeps an upload behind the last
@@ -130,10 +128,29 @@ int ssdseg_upload_async(ssdseg_ctx* ctx, void* dst, const void* src_host, size_t
 int ssdseg_upload_join(ssdseg_ctx* ctx);
 int ssdseg_upload_sync(ssdseg_ctx* ctx);
 
-int ssdseg_graph_begin(ssdseg_ctx* ctx);
-int ssdseg_graph_end(ssdseg_ctx* ctx, void** graph_exec_host);
-int ssdseg_graph_launch(ssdseg_ctx* ctx, void* graph_exec);
-int ssdseg_graph_destroy(ssdseg_ctx* ctx, void* graph_exec);
+/* ---------------------------------------------------------------- data parallelism (new: SURVEY.md 8(e))
+ * The reference has no distributed code (single-process Keras fit, NB03#cell16); the boundary replaced is what
+ * tf.distribute.MirroredStrategy would do around NB03#cell14-16: per-replica BatchNormalization statistics and mining pool
+ * (losses.py:74-75,113,127), ONE sum-all-reduce of the gradients per step.  One process per GPU; RCCL over xGMI (librccl.so is
+ * dlopen'ed at the first call below).  Rank 0 obtains a 128-byte id and hands it to the other ranks by any host-side means
+ * (ssdseglib/_parallel.py: a file next to MASTER_PORT); every rank then calls ssdseg_comm_init_rank -- a collective call.
+ * (SURVEY.md 8(b2) sketched `ssdseg_comm_init_all`, the single-process / all-devices form; the bench contract is one process
+ * per GPU, hence init_rank.) */
+#define SSDSEG_COMM_ID_BYTES 128
+enum { SSDSEG_COMM_F32 = 0, SSDSEG_COMM_F64 = 1 };
+enum { SSDSEG_COMM_SUM = 0, SSDSEG_COMM_MAX = 1 };
+int ssdseg_comm_unique_id(void* id_host, size_t id_bytes);
+int ssdseg_comm_init_rank(ssdseg_ctx* ctx, const void* id_host, size_t id_bytes, int rank, int world);
+int ssdseg_comm_destroy(ssdseg_ctx* ctx);
+int ssdseg_comm_info(ssdseg_ctx* ctx, int* rank_host, int* world_host);
+/* The step's one collective, stream-ordered behind the backward pass (joins the weight-gradient side stream first):
+ * grads[count] <- sum over ranks (ssdseg_adam_step's grad_scale = 1/world makes it the mean);
+ * state[state_count] <- MEAN over ranks (BatchNormalization moving_mean / moving_variance, models.py:66,89,111: every replica
+ * updates them from its own shard, the average keeps replicas and checkpoints identical).  Either may be NULL / 0. */
+int ssdseg_allreduce_grads(ssdseg_ctx* ctx, float* grads, size_t count, float* state, size_t state_count);
+/* in-place all-reduce of a small device buffer (timing max over ranks, barriers) and broadcast from `root` */
+int ssdseg_allreduce(ssdseg_ctx* ctx, void* buf, size_t count, int dtype, int op);
+int ssdseg_broadcast(ssdseg_ctx* ctx, float* buf, size_t count, int root);
 
 /* ---------------------------------------------------------------- K1+K2: stem conv
  * Conv2D 3x3 stride 2 SAME on the rescaled image, tiny Cin (models.py:187 Rescaling x/127.5-1, :196 -> :65;

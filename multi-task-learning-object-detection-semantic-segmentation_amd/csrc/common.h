@@ -17,8 +17,11 @@ struct ssdseg_ctx {
     size_t workspace_bytes;
     size_t ws_reserved;   // front part of the workspace held by a composite entry point while it calls others (runtime.hip)
     int num_cus;
-    bool capturing;
     ssdseg_timing* timing;  // non-null while kernel timing is enabled
+    // bytes of the SECOND tensor of a BatchNorm-backward gradient view (the raw forward output y next to g) read by the next
+    // launch: not part of SURVEY.md 8(d)'s algorithmic bytes (read X, read dY, write dX), reported separately as `view_bytes`.
+    // Set by a launcher right before SSDSEG_LAUNCH*, consumed (and cleared) by ssdseg_timing_begin.
+    double timing_view_bytes;
     // Side stream for work that is off the critical path of the backward pass (weight gradients: nothing reads dW before the
     // optimizer).  ssdseg_side_begin() makes the side stream wait for everything queued so far and redirects `stream` /
     // `workspace` to it; ssdseg_side_end() restores them; ssdseg_join() makes the main stream wait for the side work and is
@@ -31,6 +34,9 @@ struct ssdseg_ctx {
     // copy stream (created on first use): host -> device staging uploads that overlap the running step (runtime.hip)
     hipStream_t copy_stream;
     hipEvent_t ev_copy_fork, ev_copy_join;
+    // RCCL communicator of this rank (comm.hip; ncclComm_t behind a void* so that only comm.hip needs the RCCL header)
+    void* comm;
+    int comm_rank, comm_world;
 };
 
 extern "C" {
@@ -63,7 +69,7 @@ const char* ssdseg_intern(const char* name);
 
 void ssdseg_set_error(const char* fmt, ...);
 int ssdseg_hip_fail(hipError_t e, const char* what);
-// workspace of at least `bytes` (grows with hipMalloc when not capturing; error while capturing)
+// workspace of at least `bytes` (grows with hipMalloc)
 int ssdseg_workspace(ssdseg_ctx* ctx, size_t bytes, void** out);
 
 #define SSDSEG_HIP(call)                                      \

@@ -383,9 +383,11 @@ int dw_bwd_impl(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, const ss
     dw_geometry(n, h, wdt, c, stride, dilation, &g, &l);
     ViewDev v{in->x, in->scale, in->shift, in->act};
     GViewDev gv{dy->g, dy->y, dy->scale, dy->shift, dy->k1, dy->k0, dy->act};
-    // algorithmic traffic: read X, read dY (a BatchNorm-backward gradient view is two tensors, g and y), write dX,
-    // read W, write dW
-    const double cost_bytes = 4.0 * (2.0 * n * h * wdt * c + (dy->scale != nullptr ? 2.0 : 1.0) * n * g.ho * g.wo * c + 18.0 * c);
+    // algorithmic traffic, SURVEY.md 8(d): 4 * (2*X + Y + 18*C) -- read X, read dY, write dX, read W, write dW.  A BatchNorm-backward
+    // gradient view is formed from TWO tensors (g and the raw forward output y): the second one is what this design reads on top
+    // of 8(d)'s ideal and is reported separately (`view_bytes`), never inside the roofline's algorithmic bytes.
+    const double cost_bytes = 4.0 * (2.0 * n * h * wdt * c + (double)n * g.ho * g.wo * c + 18.0 * c);
+    ctx->timing_view_bytes = dy->scale != nullptr ? 4.0 * n * g.ho * g.wo * c : 0.0;
     const double cost_flops = 36.0 * n * g.ho * g.wo * c;
     const int choice = dw_bwd_choice();
     // atrous (stride 1, SAME: pad == dilation): dilation^2 interleaved dense convs through the same marching kernel

@@ -99,7 +99,8 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 // chip twice anyway) and ran 10-25 % SLOWER with the tight allocation.  Dispatch: rows >= ROWA_OCC_ROWS.
 constexpr int rowa_min_waves(int WN, int MODE, int NT) { return NT > 0 ? 2 : (WN >= 2 ? 2 : (MODE == 0 ? 4 : 3)); }
 constexpr int ROWA_OCC_ROWS = 150000;
-inline long long occ_rows() { static const long long v = getenv("SSDSEG_OCC_ROWS") ? atoll(getenv("SSDSEG_OCC_ROWS")) : ROWA_OCC_ROWS; return v; }
+// (read on every call, like the other dispatch switches: the parity tests flip it between calls to force either instantiation)
+inline long long occ_rows() { const char* e = getenv("SSDSEG_OCC_ROWS"); return e != nullptr ? atoll(e) : ROWA_OCC_ROWS; }
 template <int WN, int MODE, int LD, int NT = 0, int EP = 0, int OCC = 0>
 __global__ void __launch_bounds__(256, OCC ? rowa_min_waves(WN, MODE, NT) : 1) gemm_rowA_kernel(RowAArgs p) {
     constexpr bool CONV = LD == 1, STEM = LD == 2, FUSEW = NT > 0, F4 = EP >= 1, BNE = EP == 2;
@@ -956,11 +957,14 @@ int launch_rowA(ssdseg_ctx* ctx, const RowAArgs& a0) {
     size_t lds = (size_t)(BM * AS + BK * (32 * wn + 1)) * sizeof(float);
     size_t red = (size_t)(4 * 2 * 32 * wn) * sizeof(float);
     if (red > lds) lds = red;
-    // algorithmic: read the streamed operand and the weights once, write the output once; a BatchNorm-backward gradient view
-    // is formed from TWO tensors (g and the raw forward output y), both of which have to be read
-    const double streamed = (MODE == 1 && a.cs != nullptr) ? 2.0 : 1.0;
-    const double cost_bytes = 4.0 * (streamed * a.I * a.R + (double)a.I * a.J + (double)a.R * a.J);
+    // algorithmic: read the streamed operand and the weights once, write the output once.  The dense 3x3 conv
+    // (LD == 1) streams its input ONCE per 8(d) -- X + Y + W, not the nine-fold im2col operand the implicit GEMM walks (a.R =
+    // 9 * channels).  The second tensor of a BatchNorm-backward gradient view (raw y next to g) is reported as `view_bytes`.
+    const double red_once = LD == 1 ? (double)a.convC : (double)a.R;
+    const double cost_bytes = 4.0 * ((double)a.I * red_once + (double)a.I * a.J + (double)a.R * a.J);
     const double cost_flops = 2.0 * a.I * a.R * a.J;
+    const double view_bytes = (MODE == 1 && a.cs != nullptr) ? 4.0 * a.I * red_once : 0.0;
+    ctx->timing_view_bytes = view_bytes;
     const bool occ = a.I >= occ_rows();
     char kbuf[64];
     // Measured per layer on MI355X (profiles/r01_wres_vs_general_per_layer.txt): the resident kernel wins when every wave
@@ -1051,8 +1055,9 @@ int launch_wgrad_wn(ssdseg_ctx* ctx, const WGradArgs& a, int wn, dim3 grid) {
     size_t red = (size_t)(WR - 1) * WI * wn * 16 * 64 * sizeof(float);
     if (red > lds) lds = red;
     const double share = 1.0 / ((double)grid.x * grid.y);   // every (k-tile, n-tile) block column re-reads its operands
-    const double cost_bytes = 4.0 * ((double)a.M * a.K + (a.gs != nullptr ? 2.0 : 1.0) * a.M * a.N + (double)a.K * a.N);
+    const double cost_bytes = 4.0 * ((double)a.M * a.K + (double)a.M * a.N + (double)a.K * a.N);   // 8(d): read X, read dY, write dW
     const double cost_flops = 2.0 * a.M * a.K * a.N;
+    ctx->timing_view_bytes = a.gs != nullptr ? 4.0 * a.M * a.N : 0.0;
     (void)share;
     char kbuf[64];
     snprintf(kbuf, sizeof(kbuf), "gemm_wgrad_kernel<%d, %d, %d>%s", WI, WR, wn, a.convH > 0 ? " [conv3x3 tap]" : "");
@@ -1087,8 +1092,10 @@ int wgrad_run(ssdseg_ctx* ctx, WGradArgs a, float* dw) {
     const int jtiles = cdiv(n, 32 * wn);
     // target blocks per CU: the long-M (HBM-bound) layers want more, shorter splits in flight; the short-M ones fewer, longer
     // splits (half the partial slabs, prologue / epilogue amortised over more steps)
-    static const long long bpc_long = getenv("SSDSEG_WGRAD_BPC_LONG") ? atoll(getenv("SSDSEG_WGRAD_BPC_LONG")) : 4;
-    static const long long bpc_short = getenv("SSDSEG_WGRAD_BPC") ? atoll(getenv("SSDSEG_WGRAD_BPC")) : 2;
+    const char* el = getenv("SSDSEG_WGRAD_BPC_LONG");   // (read per call: tests / A-B runs flip them inside one process)
+    const char* es = getenv("SSDSEG_WGRAD_BPC");
+    const long long bpc_long = el != nullptr ? atoll(el) : 4;
+    const long long bpc_short = es != nullptr ? atoll(es) : 2;
     const long long bpc = m >= ROWA_OCC_ROWS ? bpc_long : bpc_short;
     long long want = (bpc * ctx->num_cus + (long long)itiles * jtiles - 1) / ((long long)itiles * jtiles);
     long long splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
@@ -1319,9 +1326,9 @@ int ssdseg_pwconv_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssd
     a.wpart = (float*)ws;
     const dim3 grid(1, gy, 1);
     const size_t lds = (size_t)(BM * AS + BK * 33) * sizeof(float);
-    const double streamed = dy->scale != nullptr ? 2.0 : 1.0;
-    const double cost_bytes = 4.0 * (streamed * m * n + 2.0 * m * k + 2.0 * k * n);
+    const double cost_bytes = 4.0 * ((double)m * n + 2.0 * m * k + 2.0 * k * n);   // 8(d): read dY, read X, write dX, read W, write dW
     const double cost_flops = 4.0 * m * k * n;
+    ctx->timing_view_bytes = dy->scale != nullptr ? 4.0 * m * n : 0.0;
     const int nt = cdiv(n, 32);
     const size_t wl = wres_enabled() ? wres_lds_bytes(n, 1) : 0;
     if (wl > 0) {
@@ -1432,8 +1439,11 @@ int ssdseg_pwconv_bwd_bn(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const 
     size_t lds = (size_t)(BM * AS + BK * (32 * wn + 1)) * sizeof(float);
     const size_t cs = (size_t)64 * (32 * wn + 4) * sizeof(float);
     if (cs > lds) lds = cs;
-    const double cost_bytes = 4.0 * ((dy->scale != nullptr ? 2.0 : 1.0) * m * n + 2.0 * m * k + (double)k * n);
+    // 8(d): read dY, write dX, read W; the raw input tensor read by the fused BatchNorm-backward epilogue replaces that BN's own
+    // reduction pass and is counted with the gradient view's second tensor as `view_bytes`
+    const double cost_bytes = 4.0 * ((double)m * n + (double)m * k + (double)k * n);
     const double cost_flops = 2.0 * m * k * n;
+    ctx->timing_view_bytes = 4.0 * ((dy->scale != nullptr ? (double)m * n : 0.0) + (double)m * k);
     const bool occ = m >= occ_rows();
     char kbuf[64];
     snprintf(kbuf, sizeof(kbuf), "gemm_rowA_kernel<%d, 1, 0, 0, 2, %d>", wn, (int)occ);
@@ -1718,7 +1728,8 @@ int ssdseg_conv3x3_bwd_weight(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, c
         const dim3 grid(gx, gy, (unsigned)splits);
         const size_t lds = (size_t)(C9_PX * (32 * wn + 4) + 3 * C9_XW * C9_XS) * sizeof(float);
         const double m = (double)n * h * wdt;
-        const double cost_bytes = 4.0 * (m * cin + (dy->scale != nullptr ? 2.0 : 1.0) * m * cout + 9.0 * cin * cout);
+        const double cost_bytes = 4.0 * (m * cin + m * cout + 9.0 * cin * cout);   // 8(d): X + dY + dW
+        ctx->timing_view_bytes = dy->scale != nullptr ? 4.0 * m * cout : 0.0;
         const double cost_flops = 18.0 * m * cin * cout;
         const char* w12 = getenv("SSDSEG_CONV3_WGRAD");   // "nine": the nine-wave kernel for the 128-column tiles as well
         if (wn == 4 && !(w12 != nullptr && !strcmp(w12, "nine")))

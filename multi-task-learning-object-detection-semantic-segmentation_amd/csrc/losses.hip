@@ -14,6 +14,7 @@ constexpr float KEPS = 1e-7f;
 constexpr int BPI = 16;  // blocks per image in the per-anchor passes
 
 __device__ __forceinline__ float clipf(float p) { return fminf(fmaxf(p, KEPS), 1.f - KEPS); }
+__device__ __forceinline__ float logcr(float p) { return (float)log((double)p); }
 __device__ __forceinline__ float insidef(float p) { return (p >= KEPS && p <= 1.f - KEPS) ? 1.f : 0.f; }
 
 __device__ __forceinline__ unsigned order_key(float v) {
@@ -44,7 +45,12 @@ __device__ __forceinline__ AnchorTerms anchor_terms(float4 yl, float4 p, float4 
     AnchorTerms t;
     t.is_bg = yl.x;
     t.not_bg = fabsf(yl.x - 1.f);
-    t.ce = -(yl.x * logf(clipf(p.x)) + yl.y * logf(clipf(p.y)) + yl.z * logf(clipf(p.z)) + yl.w * logf(clipf(p.w)));
+    // The per-anchor cross-entropy is the KEY of the batch-global hard-negative selection (losses.py:127-135): two background
+    // anchors whose probabilities differ in the last bits are ranked by the float32 value of log().  logf() is a <= 1 ulp
+    // approximation whose last bit differs between math libraries (ocml here, NumPy / Eigen elsewhere), which would make the
+    // selected SET library-dependent.  The key is therefore defined as the correctly rounded float32 logarithm, obtained as
+    // float(log(double(p))) -- reproducible by any host with an IEEE double log (the oracle does the same).
+    t.ce = -(yl.x * logcr(clipf(p.x)) + yl.y * logcr(clipf(p.y)) + yl.z * logcr(clipf(p.z)) + yl.w * logcr(clipf(p.w)));
     t.loc_nb = (fabsf(yb.x) + fabsf(yb.y) + fabsf(yb.z) + fabsf(yb.w)) > 0.f ? 1.f : 0.f;
     const float e[4] = {yb.x - pb.x, yb.y - pb.y, yb.z - pb.z, yb.w - pb.w};
     float s = 0.f;

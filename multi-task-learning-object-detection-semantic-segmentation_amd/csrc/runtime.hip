@@ -1,4 +1,4 @@
-// Context, device memory, events and hipGraph capture behind the C-ABI (include/ssdseg.h).
+// Context, device memory, streams, events and kernel timing behind the C-ABI (include/ssdseg.h).
 #include <stdarg.h>
 
 #include "common.h"
@@ -30,11 +30,6 @@ int ssdseg_workspace(ssdseg_ctx* ctx, size_t bytes, void** out) {
             ssdseg_set_error("nested workspace request of %zu bytes exceeds the composite call's reservation (%zu)", bytes, ctx->workspace_bytes);
             return SSDSEG_EINVAL(0);
         }
-        if (ctx->capturing) {
-            ssdseg_set_error("workspace of %zu bytes needed during graph capture (have %zu): call ssdseg_ctx_reserve first",
-                             bytes, ctx->workspace_bytes);
-            return SSDSEG_EINVAL(0);
-        }
         // the old workspace may still be in use by queued kernels
         SSDSEG_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->workspace) SSDSEG_HIP(hipFree(ctx->workspace));
@@ -57,11 +52,11 @@ struct ssdseg_timing {
     struct Pending {
         const char* kernel;
         hipEvent_t start, stop;
-        double bytes, flops;
+        double bytes, flops, view_bytes;
     };
     struct Stat {
         long long count = 0;
-        double ms = 0, bytes = 0, flops = 0;
+        double ms = 0, bytes = 0, flops = 0, view_bytes = 0;
     };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> pool;
@@ -93,7 +88,10 @@ static hipEvent_t timing_event(ssdseg_timing* t) {
 static void timing_fold(ssdseg_ctx* ctx) {
     ssdseg_timing* t = ctx->timing;
     if (!t || t->pending.empty()) return;
+    // events may sit on either stream (a weight-gradient launch is bracketed on the side stream): wait for both, otherwise a
+    // pair that is still "not ready" would be dropped from the statistics without a trace
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
     for (auto& p : t->pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
@@ -102,6 +100,7 @@ static void timing_fold(ssdseg_ctx* ctx) {
             s.ms += ms;
             s.bytes += p.bytes;
             s.flops += p.flops;
+            s.view_bytes += p.view_bytes;
         }
         t->pool.push_back(p.start);
         t->pool.push_back(p.stop);
@@ -111,19 +110,21 @@ static void timing_fold(ssdseg_ctx* ctx) {
 
 void ssdseg_timing_begin(ssdseg_ctx* ctx, const char* kernel, double bytes, double flops) {
     ssdseg_timing* t = ctx->timing;
-    if (!t || ctx->capturing) return;
+    const double view_bytes = ctx->timing_view_bytes;
+    ctx->timing_view_bytes = 0.0;
+    if (!t) return;
     t->open = false;
     if (!t->filter.empty() && t->filter != kernel) return;
     t->open = true;
     if (t->pending.size() >= 8192) timing_fold(ctx);
-    ssdseg_timing::Pending p{kernel, timing_event(t), timing_event(t), bytes, flops};
+    ssdseg_timing::Pending p{kernel, timing_event(t), timing_event(t), bytes, flops, view_bytes};
     (void)hipEventRecord(p.start, ctx->stream);
     t->pending.push_back(p);
 }
 
 void ssdseg_timing_end(ssdseg_ctx* ctx) {
     ssdseg_timing* t = ctx->timing;
-    if (!t || ctx->capturing || !t->open || t->pending.empty()) return;
+    if (!t || !t->open || t->pending.empty()) return;
     t->open = false;
     (void)hipEventRecord(t->pending.back().stop, ctx->stream);
 }
@@ -160,7 +161,7 @@ int ssdseg_timing_reset(ssdseg_ctx* ctx) {
     return 0;
 }
 
-// Writes "kernel\tcount\ttotal_ms\talgorithmic_bytes\tflops\n" lines; returns SSDSEG_EINVAL(3) if buf is too small.
+// Writes "kernel\tcount\ttotal_ms\talgorithmic_bytes\tflops\tview_bytes\n" lines; returns SSDSEG_EINVAL(3) if buf is too small.
 int ssdseg_timing_report(ssdseg_ctx* ctx, char* buf_host, size_t buf_len) {
     SSDSEG_ARG(ctx != nullptr, 1);
     SSDSEG_ARG(buf_host != nullptr && buf_len > 0, 2);
@@ -169,8 +170,8 @@ int ssdseg_timing_report(ssdseg_ctx* ctx, char* buf_host, size_t buf_len) {
     timing_fold(ctx);
     size_t used = 0;
     for (auto& kv : ctx->timing->stats) {
-        int n = snprintf(buf_host + used, buf_len - used, "%s\t%lld\t%.6f\t%.0f\t%.0f\n", kv.first.c_str(), kv.second.count, kv.second.ms,
-                         kv.second.bytes, kv.second.flops);
+        int n = snprintf(buf_host + used, buf_len - used, "%s\t%lld\t%.6f\t%.0f\t%.0f\t%.0f\n", kv.first.c_str(), kv.second.count, kv.second.ms,
+                         kv.second.bytes, kv.second.flops, kv.second.view_bytes);
         if (n < 0 || (size_t)n >= buf_len - used) {
             ssdseg_set_error("ssdseg_timing_report: buffer of %zu bytes is too small", buf_len);
             return SSDSEG_EINVAL(3);
@@ -206,8 +207,8 @@ int ssdseg_ctx_create(int device, void* stream, ssdseg_ctx** out_host) {
     c->workspace = nullptr;
     c->workspace_bytes = 0;
     c->num_cus = prop.multiProcessorCount;
-    c->capturing = false;
     c->timing = nullptr;
+    c->timing_view_bytes = 0.0;
     c->side_stream = nullptr;
     c->ev_fork = c->ev_join = nullptr;
     c->side_workspace = nullptr;
@@ -215,6 +216,9 @@ int ssdseg_ctx_create(int device, void* stream, ssdseg_ctx** out_host) {
     c->side_ok = c->side_on = c->side_pending = false;
     c->copy_stream = nullptr;
     c->ev_copy_fork = c->ev_copy_join = nullptr;
+    c->comm = nullptr;
+    c->comm_rank = 0;
+    c->comm_world = 1;
     if (stream) {
         c->stream = (hipStream_t)stream;
         c->owns_stream = false;
@@ -244,7 +248,7 @@ int ssdseg_ctx_create(int device, void* stream, ssdseg_ctx** out_host) {
 }
 
 bool ssdseg_side_begin(ssdseg_ctx* c) {
-    if (!c->side_ok || c->capturing || c->side_on) return false;
+    if (!c->side_ok || c->side_on) return false;
     if (hipEventRecord(c->ev_fork, c->stream) != hipSuccess) return false;
     if (hipStreamWaitEvent(c->side_stream, c->ev_fork, 0) != hipSuccess) return false;
     std::swap(c->stream, c->side_stream);
@@ -277,6 +281,7 @@ int ssdseg_ctx_destroy(ssdseg_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)ssdseg_join(ctx);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm) (void)ssdseg_comm_destroy(ctx);
     ssdseg_timing_enable(ctx, 0);
     if (ctx->workspace) (void)hipFree(ctx->workspace);
     if (ctx->side_workspace) (void)hipFree(ctx->side_workspace);
@@ -412,7 +417,6 @@ int ssdseg_host_free(ssdseg_ctx* ctx, void* ptr_host) {
 
 int ssdseg_upload_fence(ssdseg_ctx* ctx) {
     SSDSEG_ARG(ctx != nullptr, 1);
-    SSDSEG_ARG(!ctx->capturing, 1);
     int rc = copy_stream_of(ctx);
     if (rc) return rc;
     SSDSEG_HIP(hipEventRecord(ctx->ev_copy_fork, ctx->stream));
@@ -424,7 +428,6 @@ int ssdseg_upload_async(ssdseg_ctx* ctx, void* dst, const void* src_host, size_t
     if (bytes == 0) return 0;
     SSDSEG_ARG(dst != nullptr, 2);
     SSDSEG_ARG(src_host != nullptr, 3);
-    SSDSEG_ARG(!ctx->capturing, 1);
     int rc = copy_stream_of(ctx);
     if (rc) return rc;
     // the destination may still be read by main-stream work queued BEFORE the last fence (not by what came after it)
@@ -486,43 +489,6 @@ int ssdseg_event_elapsed_ms(ssdseg_ctx* ctx, void* ev_start, void* ev_stop, floa
     SSDSEG_ARG(ms_host != nullptr, 4);
     SSDSEG_HIP(hipEventSynchronize((hipEvent_t)ev_stop));
     SSDSEG_HIP(hipEventElapsedTime(ms_host, (hipEvent_t)ev_start, (hipEvent_t)ev_stop));
-    return 0;
-}
-
-int ssdseg_graph_begin(ssdseg_ctx* ctx) {
-    SSDSEG_ARG(ctx != nullptr, 1);
-    SSDSEG_ARG(!ctx->capturing, 1);
-    { int jrc = ssdseg_join(ctx); if (jrc) return jrc; }
-    SSDSEG_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-    ctx->capturing = true;
-    return 0;
-}
-
-int ssdseg_graph_end(ssdseg_ctx* ctx, void** graph_exec_host) {
-    SSDSEG_ARG(ctx != nullptr, 1);
-    SSDSEG_ARG(graph_exec_host != nullptr, 2);
-    SSDSEG_ARG(ctx->capturing, 1);
-    ctx->capturing = false;
-    hipGraph_t graph = nullptr;
-    SSDSEG_HIP(hipStreamEndCapture(ctx->stream, &graph));
-    hipGraphExec_t exec = nullptr;
-    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (e != hipSuccess) return ssdseg_hip_fail(e, "hipGraphInstantiate");
-    *graph_exec_host = (void*)exec;
-    return 0;
-}
-
-int ssdseg_graph_launch(ssdseg_ctx* ctx, void* graph_exec) {
-    SSDSEG_ARG(ctx != nullptr, 1);
-    SSDSEG_ARG(graph_exec != nullptr, 2);
-    SSDSEG_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, ctx->stream));
-    return 0;
-}
-
-int ssdseg_graph_destroy(ssdseg_ctx* ctx, void* graph_exec) {
-    SSDSEG_ARG(ctx != nullptr, 1);
-    if (graph_exec) SSDSEG_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
     return 0;
 }
 

@@ -10,7 +10,7 @@ Adam -- third-party), written around the MI355X design
   * Concatenate over channels is a write offset (producers write straight into their slice of the concat
     buffer, `ld` = total channels), Reshape/Split are metadata.
   * everything stays resident in HBM (288 GB): no recomputation, no activation re-use planning.
-  * the launch list is static, so a whole step can be captured in a hipGraph.
+  * the launch list is static (no Python-side decisions inside a step besides the op order).
 
 Manual backward replaces autodiff: every op below carries its own `bwd`.  Gradient fan-in order is the fixed
 reverse launch order (deterministic).
@@ -638,7 +638,6 @@ class Engine:
             self._lower(layer)
         self.output_vals = [self.vals[id(t)] for t in model.outputs]
         self.adam_step_count = 0
-        self._graph_exec = None
 
     # ------------------------------------------------------------------ parameters
     def _alloc_params(self, grad_bucket):

@@ -1,8 +1,7 @@
 """ctypes binding of libssdseg_hip.so (C-ABI: include/ssdseg.h) -- the only door from the Python host to the GPU.
 
 No torch, no fallbacks: if the shared library is missing or a call fails this module raises.  Device memory is
-owned by `DeviceBuffer` objects (hipMalloc/hipFree through the C-ABI), or borrowed from a raw pointer (for the
-RCCL plumbing, where the gradient bucket is a torch tensor).
+owned by `DeviceBuffer` objects (hipMalloc/hipFree through the C-ABI), or borrowed from a raw pointer.
 """
 from __future__ import annotations
 
@@ -11,6 +10,8 @@ import os
 from typing import Optional, Sequence, Tuple
 
 import numpy as np
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # this driver only does dmabuf IPC (RCCL across processes needs it)
 
 _LIB_NAME = "libssdseg_hip.so"
 _lib = None
@@ -67,10 +68,13 @@ _SIGNATURES = {
     "ssdseg_upload_async": [_vp, _vp, _vp, _sz, _i],
     "ssdseg_upload_join": [_vp],
     "ssdseg_upload_sync": [_vp],
-    "ssdseg_graph_begin": [_vp],
-    "ssdseg_graph_end": [_vp, C.POINTER(_vp)],
-    "ssdseg_graph_launch": [_vp, _vp],
-    "ssdseg_graph_destroy": [_vp, _vp],
+    "ssdseg_comm_unique_id": [_vp, _sz],
+    "ssdseg_comm_init_rank": [_vp, _vp, _sz, _i, _i],
+    "ssdseg_comm_destroy": [_vp],
+    "ssdseg_comm_info": [_vp, _ip, _ip],
+    "ssdseg_allreduce_grads": [_vp, _vp, _sz, _vp, _sz],
+    "ssdseg_allreduce": [_vp, _vp, _sz, _i, _i],
+    "ssdseg_broadcast": [_vp, _vp, _sz, _i],
     "ssdseg_stem_conv_parts": [_i, _i, _i, _i, _ip],
     "ssdseg_stem_conv_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp],
     "ssdseg_stem_conv_bwd_weight": [_vp, _vp, _GP, _vp, _vp, _i, _i, _i, _i, _i, _f, _f],
@@ -359,16 +363,16 @@ class Context:
         _check(self.lib.ssdseg_timing_reset(self.handle), "ssdseg_timing_reset")
 
     def timing_report(self):
-        """-> {kernel symbol: dict(count, ms, bytes, flops)}"""
+        """-> {kernel symbol: dict(count, ms, bytes, flops, view_bytes)}: `bytes` = SURVEY.md 8(d) algorithmic bytes, `view_bytes` =
+        the second tensor of BatchNorm-backward gradient views read on top of them"""
         buf = C.create_string_buffer(1 << 16)
         _check(self.lib.ssdseg_timing_report(self.handle, buf, len(buf)), "ssdseg_timing_report")
         out = {}
         for line in buf.value.decode().splitlines():
-            name, count, ms, nbytes, flops = line.split("\t")
-            out[name] = dict(count=int(count), ms=float(ms), bytes=float(nbytes), flops=float(flops))
+            name, count, ms, nbytes, flops, vbytes = line.split("\t")
+            out[name] = dict(count=int(count), ms=float(ms), bytes=float(nbytes), flops=float(flops), view_bytes=float(vbytes))
         return out
 
-    # ---- hipGraph capture
     # ---- overlapped uploads (copy stream)
     def upload_async(self, dst: "DeviceBuffer", src, after_fence: bool = True):
         """src: a PinnedBuffer (truly asynchronous) or a C-contiguous NumPy array (the call returns when the runtime has staged
@@ -385,20 +389,6 @@ class Context:
 
     def upload_sync(self):
         _check(self.lib.ssdseg_upload_sync(self.handle), "ssdseg_upload_sync")
-
-    def graph_begin(self):
-        _check(self.lib.ssdseg_graph_begin(self.handle), "ssdseg_graph_begin")
-
-    def graph_end(self) -> int:
-        out = C.c_void_p()
-        _check(self.lib.ssdseg_graph_end(self.handle, C.byref(out)), "ssdseg_graph_end")
-        return out.value
-
-    def graph_launch(self, g: int):
-        _check(self.lib.ssdseg_graph_launch(self.handle, g), "ssdseg_graph_launch")
-
-    def graph_destroy(self, g: int):
-        _check(self.lib.ssdseg_graph_destroy(self.handle, g), "ssdseg_graph_destroy")
 
     # ---- generic call: ctx.call("ssdseg_pwconv_fwd", view, ldx, w, y, ...) with DeviceBuffer/None/int/float args
     def call(self, name: str, *args):

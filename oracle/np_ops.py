@@ -271,7 +271,12 @@ def _clipped_log(p):
     dt = p.dtype
     lo, hi = np.asarray(EPS, dt), np.asarray(1.0, dt) - np.asarray(EPS, dt)
     inside = ((p >= lo) & (p <= hi)).astype(dt)   # clip_by_value gradient (App. B.6)
-    return np.log(np.clip(p, lo, hi)), inside
+    # float32 input: the logarithm is taken in double and rounded once -- the correctly rounded float32 log.  TF's own
+    # float32 log (Eigen) is a <= 1 ulp approximation; which last bit it returns is not knowable here, and the hard-negative
+    # selection ranks near-equal background losses by exactly that bit.  Defining the key as the correctly rounded value makes
+    # the selection reproducible across math libraries (the device kernel computes float(log(double(p))) too).
+    clipped = np.clip(p, lo, hi)
+    return np.log(clipped.astype(np.float64)).astype(dt), inside
 
 
 def cross_entropy_loss(y_true, p, class_weights):

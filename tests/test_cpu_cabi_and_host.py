@@ -123,3 +123,69 @@ def test_offline_evaluators_hand_worked(tmp_path):
     pred[0, 0, 1] = [0.5, 0.5, 0.0]
     got = ssdseglib.evaluators.jaccard_iou_semantic_segmentation(pred, [str(m)], [0, 1, 2], 0)
     assert abs(got[1] - 1.5 / 2.0) < 1e-6 and abs(got[2] - 1.0) < 1e-6 and 0 not in got   # class 1: inter 1.5, total 3.5
+
+
+def _header_prototypes():
+    """{function name: [C parameter type, ...]} parsed from include/ssdseg.h"""
+    header = open(os.path.join(REPO, "include", "ssdseg.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\bint\s+(ssdseg_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", header, flags=re.S):
+        params = [p.strip() for p in m.group(2).replace("\n", " ").split(",")]
+        params = [] if params == ["void"] else params
+        protos[m.group(1)] = [re.sub(r"\s+[A-Za-z_][A-Za-z0-9_]*$", "", p).replace(" *", "*").strip() for p in params]
+    return protos
+
+
+def test_ctypes_signatures_match_the_header(lib):
+    """every parameter of every entry point has the ctypes type its C type demands -- in particular every `ssdseg_view*` /
+    `ssdseg_gview*` is POINTER(struct), so handing a bare device pointer where a view struct is expected fails in Python
+    (ctypes.ArgumentError) instead of making the library read device memory as a host struct (round 1: a GPU abort at the next
+    synchronisation, DESIGN.md 'Fault log')."""
+    import ctypes as C
+    from ssdseglib import _hip
+
+    def expect(ctype: str):
+        t = ctype.replace("const ", "").strip()
+        if t == "ssdseg_view*":
+            return _hip._VP
+        if t == "ssdseg_gview*":
+            return _hip._GP
+        if t == "int":
+            return C.c_int
+        if t == "float":
+            return C.c_float
+        if t == "double":
+            return C.c_double
+        if t == "size_t":
+            return C.c_size_t
+        if t == "long long":
+            return C.c_longlong
+        assert t.endswith("*"), t
+        return "pointer"
+
+    protos = _header_prototypes()
+    assert len(protos) > 70
+    for name, params in protos.items():
+        if name == "ssdseg_version":
+            continue
+        sig = _hip._SIGNATURES[name]
+        assert len(sig) == len(params), f"{name}: {len(sig)} ctypes parameters for {len(params)} C parameters"
+        for i, (ct, p) in enumerate(zip(sig, params)):
+            want = expect(p)
+            if want == "pointer":
+                assert ct in (C.c_void_p, C.c_char_p) or hasattr(ct, "contents") or issubclass(ct, C._Pointer), f"{name} arg {i + 1}: {p} bound as {ct}"
+                assert ct not in (_hip._VP, _hip._GP), f"{name} arg {i + 1}: {p} bound as a view struct"
+            else:
+                assert ct is want, f"{name} arg {i + 1}: {p} bound as {ct}"
+
+
+def test_bare_pointer_where_a_view_is_expected_is_a_python_error(lib):
+    import ctypes as C
+    from ssdseglib import _hip
+    with pytest.raises(C.ArgumentError):
+        # residual is `const ssdseg_view*` (4th parameter): a raw device pointer must not be accepted
+        lib.ssdseg_bn_apply(None, C.byref(_hip.view(None)), 4, C.c_void_p(0x7f0000000000), 4, None, 4, 1, 4)
+    with pytest.raises(C.ArgumentError):
+        lib.ssdseg_pwconv_fwd(None, C.c_void_p(0x7f0000000000), 4, None, None, 4, 1, 4, 4, None)
+    assert lib.ssdseg_bn_apply(None, C.byref(_hip.view(None)), 4, None, 4, None, 4, 1, 4) == -1001   # reaches C: ctx == NULL -> EINVAL(1)
