@@ -217,7 +217,7 @@ int ssdseg_pwconv_bwd_bn(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const 
 
 /* ---------------------------------------------------------------- K6: dense 3x3 stride 1 SAME (implicit GEMM)
  * Conv2D 3x3 in the DeepLabV3+ decoder (blocks.py:117,127).  w: [3][3][cin][cout]. */
-int ssdseg_conv3x3_parts(int n, int h, int w, int cout, int* nparts_host);
+int ssdseg_conv3x3_parts(int n, int h, int w, int cin, int cout, int* nparts_host);
 int ssdseg_conv3x3_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const float* w, float* y, int n, int h,
                        int wdt, int cin, int cout, float* stats);
 int ssdseg_conv3x3_bwd_data(ssdseg_ctx* ctx, const ssdseg_gview* dy, const float* w, float* dx, int ldx, int n,

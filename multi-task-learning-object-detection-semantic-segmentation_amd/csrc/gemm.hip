@@ -835,6 +835,8 @@ int rowA_wn(int rows, int cols) { return pick_wn(cols, cdiv(rows, BM)); }
 
 #include "gemm_wres.h"
 #include "conv3_wgrad.h"
+#include "conv3_tile.h"
+#include "conv3_wgrad_tile.h"
 
 // 1: the resident kernels where they measured faster (default); 0: SSDSEG_NO_WRES=1, general kernels everywhere (A/B
 // measurements); 2: SSDSEG_WRES_FORCE=1, resident kernels for every shape that fits (the parity tests run that way)
@@ -1218,6 +1220,63 @@ int conv3n_scratch(ssdseg_ctx* ctx, size_t bytes, void** out) {
     return ssdseg_workspace(ctx, bytes + bytes / 2 + ((size_t)64 << 20), out);
 }
 
+
+// ---- halo-tile 3x3 conv (conv3_tile.h): geometry and launch
+bool conv3_tile_enabled() {
+    const char* e = getenv("SSDSEG_CONV3_TILE");   // "0": the implicit-GEMM kernels (A/B measurements, parity tests)
+    return !(e != nullptr && e[0] == '0');
+}
+bool conv3_tile_fwd_ok(int cin, int cout) { return conv3_tile_enabled() && !conv3_narrow(cin, cout) && cin % C3T_KC == 0; }
+// 32-bit buffer offsets: the streamed tensor (row stride ld) has to stay below 2^31 bytes
+bool conv3_tile_fits(int n, int h, int w, int ld) { return (long long)n * h * w * ld * 4 < (1LL << 31); }
+
+struct Conv3TGeom {
+    int tiles_h, tiles_w, mtiles, ntiles_n, ncols, wn;
+};
+Conv3TGeom conv3t_geometry(int n, int h, int w, int nout) {
+    Conv3TGeom g;
+    g.tiles_h = cdiv(h, C3T_ROWS);
+    g.tiles_w = cdiv(w, C3T_COLS);
+    g.mtiles = n * g.tiles_h * g.tiles_w;
+    g.ntiles_n = cdiv(nout, 160);
+    g.ncols = (cdiv(nout, g.ntiles_n) + 3) / 4 * 4;
+    g.wn = cdiv(g.ncols, 32);
+    return g;
+}
+
+template <int WN>
+int conv3t_launch_wn(ssdseg_ctx* ctx, const Conv3TArgs& a, const Conv3TGeom& g, double cost_bytes, double cost_flops) {
+    const size_t lds = conv3t_lds_floats(WN, a.cred) * sizeof(float);
+    static size_t configured = 0;   // dynamic LDS beyond 64 KiB has to be announced once per kernel
+    if (lds > configured) {
+        SSDSEG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_tile_kernel<WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    char kbuf[64];
+    snprintf(kbuf, sizeof(kbuf), "conv3_tile_kernel<%d>%s", WN, a.flip ? " [bwd_data]" : " [fwd]");
+    const char* kname = ctx->timing ? ssdseg_intern(kbuf) : "";
+    SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (conv3_tile_kernel<WN>), dim3((unsigned)(g.mtiles * g.ntiles_n)), dim3(C3T_THREADS), lds, a);
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+int conv3t_launch(ssdseg_ctx* ctx, Conv3TArgs a) {
+    const Conv3TGeom g = conv3t_geometry(a.n, a.h, a.w, a.nout);
+    a.tiles_h = g.tiles_h; a.tiles_w = g.tiles_w; a.ntiles_n = g.ntiles_n; a.ncols = g.ncols;
+    a.in_bytes = (unsigned)((((long long)a.n * a.h * a.w - 1) * a.ldi + a.cred) * 4);
+    a.wt_bytes = (unsigned)((long long)9 * a.nout * a.cred * 4);
+    const double m = (double)a.n * a.h * a.w;
+    const double cost_bytes = 4.0 * (m * a.cred + m * a.nout + 9.0 * a.cred * a.nout);   // X + Y + W
+    const double cost_flops = 18.0 * m * a.cred * a.nout;
+    switch (g.wn) {
+        case 1: return conv3t_launch_wn<1>(ctx, a, g, cost_bytes, cost_flops);
+        case 2: return conv3t_launch_wn<2>(ctx, a, g, cost_bytes, cost_flops);
+        case 3: return conv3t_launch_wn<3>(ctx, a, g, cost_bytes, cost_flops);
+        case 4: return conv3t_launch_wn<4>(ctx, a, g, cost_bytes, cost_flops);
+        default: return conv3t_launch_wn<5>(ctx, a, g, cost_bytes, cost_flops);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1574,11 +1633,13 @@ int ssdseg_stem_conv_bwd_weight(ssdseg_ctx* ctx, const float* x, const ssdseg_gv
 }
 
 // ------------------------------------------------------------------------------------------------ dense 3x3 (K6)
-int ssdseg_conv3x3_parts(int n, int h, int w, int cout, int* nparts_host) {
+int ssdseg_conv3x3_parts(int n, int h, int w, int cin, int cout, int* nparts_host) {
     SSDSEG_ARG(n > 0 && h > 0 && w > 0, 1);
-    SSDSEG_ARG(cout > 0 && cout % 4 == 0, 4);
-    SSDSEG_ARG(nparts_host != nullptr, 5);
-    *nparts_host = rowA_grid_y(n * h * w, cout);
+    SSDSEG_ARG(cin > 0 && cin % 4 == 0, 4);
+    SSDSEG_ARG(cout > 0 && cout % 4 == 0, 5);
+    SSDSEG_ARG(nparts_host != nullptr, 6);
+    // the halo-tile kernel writes one partial row per 8 x 32 pixel tile, the implicit-GEMM kernels one per row-tile slot
+    *nparts_host = conv3_tile_fwd_ok(cin, cout) ? conv3t_geometry(n, h, w, cout).mtiles : rowA_grid_y(n * h * w, cout);
     return 0;
 }
 
@@ -1608,12 +1669,27 @@ int ssdseg_conv3x3_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const fl
         ctx->ws_reserved -= wb + zb;
         if (rc) return rc;
         int nparts = 0;
-        ssdseg_conv3x3_parts(n, h, wdt, cout, &nparts);
+        ssdseg_conv3x3_parts(n, h, wdt, cin, cout, &nparts);
         const int cv = cout / 4;
         int blocks = stats != nullptr ? nparts : (int)((m * cv + 255) / 256 < 4096 ? (m * cv + 255) / 256 : 4096);
         SSDSEG_LAUNCH(ctx, 4.0 * m * (nc + cout), 0.0, conv3n_tapsum_kernel, dim3(blocks), dim3(256), 0, (const float*)z, y, n, h, wdt, cv, stats);
         SSDSEG_LAUNCH_CHECK();
         return 0;
+    }
+    if (conv3_tile_fwd_ok(cin, cout) && conv3_tile_fits(n, h, wdt, ldx)) {
+        // weights with the reduction channel contiguous: W[tap][c][n] -> Wt[tap][n][c] (2.8 MB for the decoder conv, ~3 us)
+        void* ws;
+        int rc = ssdseg_workspace(ctx, (size_t)9 * cin * cout * sizeof(float), &ws);
+        if (rc) return rc;
+        SSDSEG_LAUNCH(ctx, 8.0 * 9 * cin * cout, 0.0, conv3_transpose_w_kernel, dim3(cdiv(cout, 32), cdiv(cin, 32), 9), dim3(256), 0, w, (float*)ws, cin, cout);
+        SSDSEG_LAUNCH_CHECK();
+        Conv3TArgs t{};
+        t.in = in->x; t.cs = in->scale; t.ct = in->shift; t.act = in->act; t.ldi = ldx;
+        t.wt = (const float*)ws;
+        t.out = y; t.ldo = cout; t.accumulate = 0;
+        t.stats = stats;
+        t.n = n; t.h = h; t.w = wdt; t.cred = cin; t.nout = cout; t.flip = 0;
+        return conv3t_launch(ctx, t);
     }
     RowAArgs a{};
     a.a0 = in->x; a.cs = in->scale; a.ct = in->shift; a.act = in->act; a.lda = ldx;
@@ -1657,6 +1733,17 @@ int ssdseg_conv3x3_bwd_data(ssdseg_ctx* ctx, const ssdseg_gview* dy, const float
         rc = ssdseg_pwconv_bwd_data(ctx, &idv, nc, w2, dx, ldx, (int)m, cin, nc, nullptr, 0, accumulate);
         ctx->ws_reserved -= wb + zb;
         return rc;
+    }
+    if (conv3_tile_enabled() && dy->scale == nullptr && cout % C3T_KC == 0 && conv3_tile_fits(n, h, wdt, cout)) {
+        // dx[p][c] = sum_{tap, n} dy[p - d(tap)][n] W[tap][c][n]: the forward loop over the mirrored taps; W's native layout already has
+        // the reduction channel (n) contiguous.  (A BatchNorm gradient view is materialised by the caller first: nine taps would
+        // each re-form it -- ssdseg_gview_materialize.)
+        Conv3TArgs t{};
+        t.in = dy->g; t.act = SSDSEG_ACT_NONE; t.ldi = cout;
+        t.wt = w;
+        t.out = dx; t.ldo = ldx; t.accumulate = accumulate;
+        t.n = n; t.h = h; t.w = wdt; t.cred = cout; t.nout = cin; t.flip = 1;
+        return conv3t_launch(ctx, t);
     }
     RowAArgs a{};
     a.a0 = dy->g; a.a1 = dy->y; a.cs = dy->scale; a.ct = dy->shift; a.ck1 = dy->k1; a.ck0 = dy->k0; a.act = dy->act;
@@ -1706,6 +1793,43 @@ int ssdseg_conv3x3_bwd_weight(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, c
         return 0;
     }
     const char* c3env = getenv("SSDSEG_CONV3_WGRAD");   // "taps": the nine shifted GEMMs (A/B measurements, parity tests)
+    if (c3env == nullptr && conv3_tile_enabled() && dy->scale == nullptr && conv3_tile_fits(n, h, wdt, ldx) && conv3_tile_fits(n, h, wdt, cout)) {
+        // halo-tile form (conv3_wgrad_tile.h): 64 x 64 (k, n) tiles of all nine taps, one image row x 32 columns per step
+        Wg3TArgs a{};
+        a.x = in->x; a.xs = in->scale; a.xt = in->shift; a.xact = in->act; a.ldx = ldx;
+        a.g = dy->g;
+        a.n = n; a.h = h; a.w = wdt; a.K = cin; a.N = cout;
+        a.ktiles = cdiv(cin, W3T_KT); a.ntiles = cdiv(cout, W3T_NT);
+        a.strips = cdiv(wdt, W3T_COLS);
+        a.steps = n * a.strips * h;
+        const int tiles = a.ktiles * a.ntiles;
+        int splits = 2 * ctx->num_cus / tiles;                // two blocks per CU (67 KB of LDS, <= 256 registers each)
+        if (splits > a.steps / 4) splits = a.steps / 4;
+        if (splits < 1) splits = 1;
+        a.steps_per_split = (a.steps + splits - 1) / splits;
+        splits = (a.steps + a.steps_per_split - 1) / a.steps_per_split;
+        a.x_bytes = (unsigned)((((long long)n * h * wdt - 1) * ldx + cin) * 4);
+        a.g_bytes = (unsigned)((long long)n * h * wdt * cout * 4);
+        void* ws;
+        int rc = ssdseg_workspace(ctx, (size_t)splits * 9 * cin * cout * sizeof(float), &ws);
+        if (rc) return rc;
+        a.part = (float*)ws;
+        static bool configured = false;   // dynamic LDS beyond 64 KiB has to be announced once
+        if (!configured) {
+            SSDSEG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgrad_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3T_LDS_BYTES));
+            configured = true;
+        }
+        const double m = (double)n * h * wdt;
+        const double cost_bytes = 4.0 * (m * cin + m * cout + 9.0 * cin * cout);   // X + dY + dW
+        const double cost_flops = 18.0 * m * cin * cout;
+        SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, conv3_wgrad_tile_kernel, dim3((unsigned)(tiles * splits)), dim3(W3T_THREADS), W3T_LDS_BYTES, a);
+        SSDSEG_LAUNCH_CHECK();
+        if (splits == 1) {
+            SSDSEG_HIP(hipMemcpyAsync(dw, a.part, (size_t)9 * cin * cout * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+            return 0;
+        }
+        return ssdseg_colsum(ctx, a.part, splits, 9LL * cin * cout, dw);
+    }
     if (!(c3env != nullptr && !strcmp(c3env, "taps"))) {
         // all nine taps in one pass (conv3_wgrad.h)
         Conv9Args a{};

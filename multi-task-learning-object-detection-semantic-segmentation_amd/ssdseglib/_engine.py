@@ -280,7 +280,7 @@ class Conv3Op(Op):
         self.w, self.dw = eng.param_view(layer, "kernel"), eng.grad_view(layer, "kernel")
         s = inp.store
         if eng.training:
-            out.nparts = eng.ctx.parts("ssdseg_conv3x3_parts", s.n, s.h, s.w, out.c)
+            out.nparts = eng.ctx.parts("ssdseg_conv3x3_parts", s.n, s.h, s.w, s.c, out.c)
             out.stats = eng.ctx.empty((out.nparts, 2, out.c))
         assert out.ld == out.c
         self.out_val: Optional[Val] = None

@@ -88,7 +88,7 @@ _SIGNATURES = {
     "ssdseg_pwconv_bwd_weight": [_vp, _VP, _i, _GP, _i, _vp, _i, _i, _i],
     "ssdseg_pwconv_bwd": [_vp, _VP, _i, _GP, _i, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i],
     "ssdseg_pwconv_bwd_bn": [_vp, _VP, _i, _GP, _i, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
-    "ssdseg_conv3x3_parts": [_i, _i, _i, _i, _ip],
+    "ssdseg_conv3x3_parts": [_i, _i, _i, _i, _i, _ip],
     "ssdseg_conv3x3_fwd": [_vp, _VP, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "ssdseg_conv3x3_bwd_data": [_vp, _GP, _vp, _vp, _i, _i, _i, _i, _i, _i, _i],
     "ssdseg_conv3x3_bwd_weight": [_vp, _VP, _i, _GP, _vp, _i, _i, _i, _i, _i],

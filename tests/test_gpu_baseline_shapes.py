@@ -299,7 +299,7 @@ def test_conv3x3_decoder_at_baseline_shape(ctx):
     w64 = wgt.astype(np.float64)
     dx_, dsc, dsh, dw_ = ctx.array(x), ctx.array(sc), ctx.array(sh), ctx.array(wgt)
     dy_ = ctx.empty((n, h, w, cout))
-    nparts = ctx.parts("ssdseg_conv3x3_parts", n, h, w, cout)
+    nparts = ctx.parts("ssdseg_conv3x3_parts", n, h, w, cin, cout)
     stats = ctx.empty((nparts, 2, cout))
     ctx.call("ssdseg_conv3x3_fwd", H.view(dx_, dsc, dsh, RELU6), cin, dw_, dy_, n, h, w, cin, cout, stats)
     y = dy_.download()

@@ -39,25 +39,38 @@ def gview_inputs(rng, shape, act):
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout", [(2, 9, 11, 16, 32), (1, 12, 16, 304, 256), (2, 8, 8, 256, 4), (1, 5, 5, 24, 8), (1, 1, 1, 8, 8),
-                                            (3, 14, 40, 72, 96)])   # 40 = one full + one partial 32-pixel step per image row
-@pytest.mark.parametrize("narrow", ["1", "0"])    # cout <= 8: tap-expanded pointwise GEMMs ("1", default) vs the implicit-GEMM kernels
-def test_conv3x3_fwd_bwd(ctx, rng, monkeypatch, n, h, w, cin, cout, narrow):
+                                            (3, 14, 40, 72, 96),    # 40 = one full + one partial 32-pixel step / tile per image row
+                                            (2, 17, 33, 40, 200),   # odd number of 8-channel steps; two 100-column tiles of a 128-wide block
+                                            (1, 8, 32, 12, 16)])    # cin not a multiple of 8: the implicit-GEMM forward, halo-tile backward
+# kernel family: "narrow" = cout <= 8 as tap-expanded pointwise GEMMs (default for those shapes); "tile" = the halo-tile kernels
+# (conv3_tile.h, default for everything else); "gemm" = the implicit-GEMM kernels
+@pytest.mark.parametrize("family", ["narrow", "tile", "gemm"])
+def test_conv3x3_fwd_bwd(ctx, rng, monkeypatch, n, h, w, cin, cout, family):
     from ssdseglib import _hip as H
-    if narrow == "0" and cout > 8:
-        pytest.skip("only one kernel family for wide outputs")
-    monkeypatch.setenv("SSDSEG_CONV3_NARROW", narrow)
+    if family == "narrow" and cout > 8:
+        pytest.skip("tap-expanded form only for cout <= 8")
+    monkeypatch.setenv("SSDSEG_CONV3_NARROW", "1" if family == "narrow" else "0")
+    monkeypatch.setenv("SSDSEG_CONV3_TILE", "0" if family == "gemm" else "1")
     act = O.ACT_RELU6
     x, sc, sh, a = view_inputs(rng, (n, h, w, cin), act)
     wgt = (rng.normal(0, 1, (3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
     y_ref = O.conv2d_fwd(a.astype(np.float64), wgt.astype(np.float64))
     dx_, dsc, dsh, dw_ = ctx.array(x), ctx.array(sc), ctx.array(sh), ctx.array(wgt)
     y = ctx.empty(y_ref.shape)
-    nparts = ctx.parts("ssdseg_conv3x3_parts", n, h, w, cout)
+    nparts = ctx.parts("ssdseg_conv3x3_parts", n, h, w, cin, cout)
     stats = ctx.empty((nparts, 2, cout))
     ctx.call("ssdseg_conv3x3_fwd", H.view(dx_, dsc, dsh, act), cin, dw_, y, n, h, w, cin, cout, stats)
     assert rel_err(y.download(), y_ref) < 2e-5
     st = stats.download().astype(np.float64).sum(axis=0)
     assert rel_err(st[1], (y_ref ** 2).sum(axis=(0, 1, 2))) < 1e-4
+    assert np.abs(st[0] - y_ref.sum(axis=(0, 1, 2))).max() < 1e-4 * np.abs(y_ref).sum(axis=(0, 1, 2)).max()
+    # forward from a channel slice of a wider input buffer (the decoder conv reads the 304-channel concat)
+    ldi = cin + 8
+    xw = np.zeros((n, h, w, ldi), np.float32)
+    xw[..., 4:4 + cin] = x
+    dxw = ctx.array(xw)
+    ctx.call("ssdseg_conv3x3_fwd", H.view(dxw.view(4, (dxw.size - 4,)), dsc, dsh, act), ldi, dw_, y, n, h, w, cin, cout, None)
+    assert rel_err(y.download(), y_ref) < 2e-5
     gv, dy = gview_inputs(rng, y_ref.shape, O.ACT_RELU6)
     bufs = [ctx.array(v) for v in gv]
     dx_ref, dw_ref, _ = O.conv2d_bwd(a.astype(np.float64), wgt.astype(np.float64), dy.astype(np.float64))
@@ -68,9 +81,24 @@ def test_conv3x3_fwd_bwd(ctx, rng, monkeypatch, n, h, w, cin, cout, narrow):
     ddx.upload(base)
     ctx.call("ssdseg_conv3x3_bwd_data", H.gview(*bufs, act=O.ACT_RELU6), dw_, ddx, cin, n, h, w, cin, cout, 1)
     assert rel_err(ddx.download(), dx_ref + base) < 2e-5
+    # the engine's form: the BatchNorm gradient view materialised once, then the identity view (the halo-tile kernel's input),
+    # written into a channel slice of a wider (concat) gradient buffer, overwrite and accumulate
+    dmat = ctx.array(dy)
+    ldx = cin + 8
+    wide = ctx.zeros((n * h * w, ldx))
+    ctx.call("ssdseg_conv3x3_bwd_data", H.gview(dmat), dw_, wide.view(4, (wide.size - 4,)), ldx, n, h, w, cin, cout, 0)
+    got = wide.download().reshape(n, h, w, ldx)
+    assert rel_err(got[..., 4:4 + cin], dx_ref) < 2e-5 and np.all(got[..., :4] == 0) and np.all(got[..., 4 + cin:] == 0)
+    ctx.call("ssdseg_conv3x3_bwd_data", H.gview(dmat), dw_, wide.view(4, (wide.size - 4,)), ldx, n, h, w, cin, cout, 1)
+    assert rel_err(wide.download().reshape(n, h, w, ldx)[..., 4:4 + cin], 2 * dx_ref) < 2e-5
     ddw = ctx.empty(wgt.shape)
+    # identity gradient view (the engine's form): the halo-tile weight-gradient kernel in the "tile" family; input read from a
+    # channel slice of the wider buffer
+    ctx.call("ssdseg_conv3x3_bwd_weight", H.view(dxw.view(4, (dxw.size - 4,)), dsc, dsh, act), ldi, H.gview(dmat), ddw, n, h, w, cin, cout)
+    assert rel_err(ddw.download(), dw_ref) < 5e-5
+    ddw.upload(np.zeros(wgt.shape, np.float32))
     ctx.call("ssdseg_conv3x3_bwd_weight", H.view(dx_, dsc, dsh, act), cin, H.gview(*bufs, act=O.ACT_RELU6), ddw, n, h, w, cin, cout)
-    assert rel_err(ddw.download(), dw_ref) < 5e-5      # default: all nine taps in one pass (conv3_wgrad.h; twelve waves for cout > 32)
+    assert rel_err(ddw.download(), dw_ref) < 5e-5      # BatchNorm gradient view: all nine taps in one pass (conv3_wgrad.h; twelve waves for cout > 32)
     monkeypatch.setenv("SSDSEG_CONV3_WGRAD", "nine")   # one wave per tap for every width
     ddw.upload(np.zeros(wgt.shape, np.float32))
     ctx.call("ssdseg_conv3x3_bwd_weight", H.view(dx_, dsc, dsh, act), cin, H.gview(*bufs, act=O.ACT_RELU6), ddw, n, h, w, cin, cout)
