@@ -298,11 +298,17 @@ class Conv3Op(Op):
             o = self.out
             self.e.ctx.call("ssdseg_gview_materialize", gv, o.ld, o.m, o.c)
             gv = H.gview(o.grad)
-        self.e.ctx.side(True)      # dW is off the critical path: side stream, concurrent with the backward-data conv
+        # dW is off the critical path, but for a wide conv both backward kernels are bound by the SAME resource (the matrix pipes,
+        # 0.8 of peak each on their own): side by side they only split the CUs and thrash each other's L2.  The side stream is
+        # for pairing a weight gradient with an HBM-bound neighbour; here it is used only for the narrow (HBM-bound) 256 -> 4 conv.
+        side = self.out.c <= 8 if os.environ.get("SSDSEG_CONV3_SIDE") is None else os.environ["SSDSEG_CONV3_SIDE"] == "1"
+        if side:
+            self.e.ctx.side(True)
         try:
             self.e.ctx.call("ssdseg_conv3x3_bwd_weight", self.inp.view(), s.ld, gv, self.dw, s.n, s.h, s.w, s.c, self.out.c)
         finally:
-            self.e.ctx.side(False)
+            if side:
+                self.e.ctx.side(False)
         if s.need_grad:
             dx, acc = s.grad_slot()
             self.e.ctx.call("ssdseg_conv3x3_bwd_data", gv, self.w, dx, s.ld, s.n, s.h, s.w, s.c, self.out.c, acc)

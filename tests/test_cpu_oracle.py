@@ -237,3 +237,24 @@ def test_metrics_hand_worked():
     # intersection extent x: min(59.5, 69.5) - max(40.5, 50.5) + 1 = 10, y: 10 -> 100 / (200 + 200 - 100)
     assert np.allclose(O.metric_box_iou(t, p, cx, cy, aw, ah, (1, 1, 1, 1)), 100 / 300, atol=1e-6)
     assert np.isnan(O.metric_box_iou(np.zeros_like(t), p, cx, cy, aw, ah, (1, 1, 1, 1))[0])   # no objects: 0/0 like the reference
+
+
+
+def test_config0_single_480x640_forward_through_the_oracle():
+    """BASELINE.json configs[0] on the CPU path available here (the NumPy restatement; TensorFlow cannot be imported): one
+    480x640 image, inference mode, shapes [(1,480,640,4), (1,9600,4), (1,9600,4)] and the inference tail (1,10,6)"""
+    import bench
+    from oracle.np_model import NpModel
+    boxes, builder = bench.build_models(seed=1993)
+    model = builder.get_model_for_training('deeplabv3plus', 'ssdlite', segmentation_dilation_rates=(3, 6, 12))
+    x = np.random.default_rng(0).integers(0, 256, (1, 480, 640, 3)).astype(np.float32)
+    p_mask, p_labels, p_boxes = NpModel(model, dtype=np.float32).forward(x, training=False)
+    assert p_mask.shape == (1, 480, 640, 4) and p_labels.shape == (1, 9600, 4) and p_boxes.shape == (1, 9600, 4)
+    assert np.abs(p_mask.sum(-1) - 1).max() < 1e-5 and np.abs(p_labels.sum(-1) - 1).max() < 1e-5
+    assert p_boxes.min() >= 0 and p_boxes.max() <= 6          # quirk Q3: offsets pass ReLU6
+    inference = builder.get_model_for_inference(model_trained=model, max_number_of_boxes_per_class=4, max_number_of_boxes_per_sample=10,
+                                                boxes_iou_threshold=0.5, labels_probability_threshold=0.2, suppress_background_boxes=False,
+                                                use_segmentation_suppression=True)
+    ref = NpModel(inference, dtype=np.float32)
+    seg, det = ref.forward(x, training=False)
+    assert seg.shape == (1, 480, 640, 4) and det.shape == (1, 10, 6)
