@@ -837,6 +837,89 @@ int rowA_wn(int rows, int cols) { return pick_wn(cols, cdiv(rows, BM)); }
 #include "conv3_wgrad.h"
 #include "conv3_tile.h"
 #include "conv3_wgrad_tile.h"
+#include "pw_tile.h"
+
+// ---- tile GEMM of the pointwise convs (pw_tile.h): shape -> (waves, column tile), launch
+// SSDSEG_PW_TILE: "0" never, "1" every shape the kernel takes, unset: where it measured faster
+int pw_tile_mode() {
+    const char* e = getenv("SSDSEG_PW_TILE");
+    return e == nullptr ? 2 : (e[0] == '0' ? 0 : 1);
+}
+
+template <int WAVES, int WN, int MODE>
+int pwt_launch_inst(ssdseg_ctx* ctx, const PwTArgs& a, dim3 grid, double cost_bytes, double cost_flops) {
+    const size_t lds = pwt_lds_floats(WAVES, WN, a.cred) * sizeof(float);
+    static size_t configured = 0;
+    if (lds > configured) {
+        SSDSEG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_tile_kernel<WAVES, WN, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    char kbuf[64];
+    snprintf(kbuf, sizeof(kbuf), "pw_tile_kernel<%d, %d, %d>", WAVES, WN, MODE);
+    const char* kname = ctx->timing ? ssdseg_intern(kbuf) : "";
+    SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (pw_tile_kernel<WAVES, WN, MODE>), grid, dim3(64 * WAVES), lds, a);
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+// default dispatch rule, read off the per-layer A/B table (profiles/r02_pw_tile_vs_rowA_per_layer.txt)
+// (round 2, one MI355X, batch 32).  Forward: every layer with >= 256 output channels (the expand convs of the 30x40 / 15x20
+// stages, the ASPP branches and output conv, the decoder sepconv: 0.83-0.95 of the rowA time; project convs with <= 160 outputs
+// lose 1.0-1.9x: too few, too narrow tiles) and the 36-column tap-expanded GEMM of the 256 -> 4 logits conv (614,400 rows).
+// Input gradient: plain epilogues (no fused BatchNorm sums, no accumulation into an existing gradient: the tile kernel's scalar
+// epilogue loses there) with a reduction of <= 384 channels and a wide side (>= 256) somewhere: decoder sepconv 0.76, encoder
+// output conv 0.80, expand convs of blocks 7-10 0.84-0.93, ASPP atrous branches 0.93-0.98; long reductions onto few columns
+// (expand convs of blocks 11-16: one column tile, 75-300 blocks) lose 1.1-1.4x.
+bool pw_tile_default(int mode, long long rows, int cred, int nout, bool fused_bn, bool accumulate) {
+    if (mode == 0) return nout >= 256 || (rows >= 500000 && cred >= 256);
+    return !fused_bn && !accumulate && cred <= 384 && (nout >= 256 || cred >= 256);
+}
+
+// can the tile kernel take this GEMM?  (reduction a multiple of 8 and at least two steps deep; 32-bit buffer offsets)
+bool pw_tile_takes(long long rows, int lda, int cred, int nout) {
+    return cred % 8 == 0 && cred >= 64 && nout % 4 == 0 && rows * (long long)lda * 4 < (1LL << 31) && (long long)nout * cred * 4 < (1LL << 31);
+}
+
+// nparts_y: number of blocks along y == number of partial rows the caller sized its statistics table for (0: free choice)
+template <int MODE>
+int pw_tile_launch(ssdseg_ctx* ctx, PwTArgs a, int nparts_y, double view_bytes) {
+    const int ntiles = a.nout <= 160 ? 1 : cdiv(a.nout, 256);
+    a.ncols = (cdiv(a.nout, ntiles) + 3) / 4 * 4;
+    int wn = cdiv(a.ncols, 32);
+    const bool big = a.M >= 65536;                       // >= 256 row tiles of 256 rows: eight-wave blocks, one per CU
+    // column tiles of <= 160: four-wave blocks (two blocks per CU), and the input-gradient kernel whatever its size (its gradient
+    // view staging and epilogue need ~60 registers more: 6- and 8-tile instantiations spill)
+    if ((!big || MODE == 1) && wn > 5) {
+        const int nt2 = cdiv(a.nout, 160);
+        a.ncols = (cdiv(a.nout, nt2) + 3) / 4 * 4;
+        wn = cdiv(a.ncols, 32);
+    }
+    const int gx = cdiv(a.nout, a.ncols);
+    const int bm = big ? 256 : 128;
+    const int mtiles = cdiv(a.M, bm);
+    int gy = nparts_y > 0 ? nparts_y : (mtiles < 1024 ? mtiles : 1024);
+    if (gy > mtiles && nparts_y == 0) gy = mtiles;
+    a.a_bytes = (unsigned)((((long long)a.M - 1) * a.lda + a.cred) * 4);
+    a.wt_bytes = (unsigned)((long long)a.nout * a.cred * 4);
+    const dim3 grid(gx, gy, 1);
+    const double cost_bytes = 4.0 * ((double)a.M * a.cred + (double)a.M * a.nout + (double)a.cred * a.nout);
+    const double cost_flops = 2.0 * a.M * a.cred * a.nout;
+    ctx->timing_view_bytes = view_bytes;
+#define PWT_CASE(W, N) return pwt_launch_inst<W, N, MODE>(ctx, a, grid, cost_bytes, cost_flops)
+    if (big) {
+        if (wn <= 2) PWT_CASE(8, 2);
+        if (wn <= 4) PWT_CASE(8, 4);
+        if (wn == 5) PWT_CASE(8, 5);
+        if constexpr (MODE == 0) {
+            if (wn == 6) PWT_CASE(8, 6);
+            PWT_CASE(8, 8);
+        }
+    }
+    if (wn <= 2) PWT_CASE(4, 2);
+    if (wn <= 4) PWT_CASE(4, 4);
+    PWT_CASE(4, 5);
+#undef PWT_CASE
+}
 
 // 1: the resident kernels where they measured faster (default); 0: SSDSEG_NO_WRES=1, general kernels everywhere (A/B
 // measurements); 2: SSDSEG_WRES_FORCE=1, resident kernels for every shape that fits (the parity tests run that way)
@@ -920,6 +1003,24 @@ int launch_rowA(ssdseg_ctx* ctx, const RowAArgs& a0) {
     RowAArgs a = a0;
     int wn = rowA_wn(a.I, a.J);
     const int nparts = rowA_grid_y(a.I, a.J);   // BN-statistics partial rows the caller allocated: fixed by (I, J) alone
+    if (LD == 0 && pw_tile_mode() != 0 && pw_tile_takes(a.I, a.lda, a.R, a.J) && (pw_tile_mode() == 1 || pw_tile_default(MODE, a.I, a.R, a.J, false, a.accumulate != 0 || a.residual != nullptr))) {
+        PwTArgs t{};
+        t.a0 = a.a0; t.a1 = (MODE == 1 && a.cs != nullptr) ? a.a1 : a.a0;
+        t.cs = a.cs; t.ct = a.ct; t.ck1 = a.ck1; t.ck0 = a.ck0; t.act = a.act; t.lda = a.lda;
+        t.out = a.out; t.ldo = a.ldo; t.residual = a.residual; t.ldr = a.ldr; t.accumulate = a.accumulate;
+        t.stats = a.stats; t.M = a.I; t.cred = a.R; t.nout = a.J;
+        t.wt = a.b;
+        if (MODE == 0) {
+            // the reduction channel must be contiguous in the staged weight rows: W[k][n] -> Wt[n][k] (one small transpose per call)
+            void* ws;
+            int rc = ssdseg_workspace(ctx, (size_t)a.R * a.J * sizeof(float), &ws);
+            if (rc) return rc;
+            SSDSEG_LAUNCH(ctx, 8.0 * a.R * a.J, 0.0, conv3_transpose_w_kernel, dim3(cdiv(a.J, 32), cdiv(a.R, 32), 1), dim3(256), 0, a.b, (float*)ws, a.R, a.J);
+            SSDSEG_LAUNCH_CHECK();
+            t.wt = (const float*)ws;
+        }
+        return pw_tile_launch<MODE>(ctx, t, a.stats != nullptr ? nparts : 0, (MODE == 1 && a.cs != nullptr) ? 4.0 * a.I * a.R : 0.0);
+    }
     int splits = 1;
     // Few row tiles and a long reduction (the 30x40 / 15x20 stages): the default picks narrow column tiles to get enough blocks,
     // so every column tile re-reads the (up to 960-wide, two-tensor) streamed operand -- 3-5x the algorithmic traffic, bound by
@@ -1480,6 +1581,25 @@ int ssdseg_pwconv_bwd_bn(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const 
         if (rc) return rc;
         return ssdseg_bn_bwd_reduce(ctx, dx, lddx, in->x, ldx, m, k, in->scale, in->shift, in_mean, in_invstd, in->act, in_dgamma, in_dbeta,
                                     in_k1, in_k0);
+    }
+    if (pw_tile_mode() != 0 && pw_tile_takes(m, ldy, n, k) && (pw_tile_mode() == 1 || pw_tile_default(1, m, n, k, true, false))) {
+        // tile GEMM with the BatchNorm-backward sums taken in its epilogue (pw_tile.h)
+        PwTArgs t{};
+        t.a0 = dy->g; t.a1 = dy->scale != nullptr ? dy->y : dy->g;
+        t.cs = dy->scale; t.ct = dy->shift; t.ck1 = dy->k1; t.ck0 = dy->k0; t.act = dy->act; t.lda = ldy;
+        t.wt = w;
+        t.out = dx; t.ldo = lddx;
+        t.M = m; t.cred = n; t.nout = k;
+        const int mt = cdiv(m, m >= 65536 ? 256 : 128);
+        const int gy = mt < 1024 ? mt : 1024;
+        void* ws;
+        rc = ssdseg_workspace(ctx, (size_t)gy * 2 * k * sizeof(float), &ws);
+        if (rc) return rc;
+        t.bn_y = in->x; t.ldby = ldx; t.bn_s = in->scale; t.bn_t = in->shift; t.bn_mean = in_mean; t.bn_istd = in_invstd; t.bn_act = in->act;
+        t.bnpart = (float*)ws;
+        rc = pw_tile_launch<1>(ctx, t, gy, 4.0 * ((dy->scale != nullptr ? (double)m * n : 0.0) + (double)m * k));
+        if (rc) return rc;
+        return ssdseg_bn_bwd_finalize_launch(ctx, t.bnpart, gy, k, (double)m, in->scale, in_mean, in_invstd, in_dgamma, in_dbeta, in_k1, in_k0);
     }
     RowAArgs a{};
     a.a0 = dy->g; a.a1 = dy->y; a.cs = dy->scale; a.ct = dy->shift; a.ck1 = dy->k1; a.ck0 = dy->k0; a.act = dy->act;

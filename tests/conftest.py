@@ -18,11 +18,15 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 KERNEL_FAMILIES = {
     "default": {},
     "general": {"SSDSEG_NO_WRES": "1", "SSDSEG_DW_FWD": "lds", "SSDSEG_DW_BWD": "lds", "SSDSEG_CONV3_WGRAD": "taps",
-                "SSDSEG_CONV3_NARROW": "0"},
-    "general-reg": {"SSDSEG_NO_WRES": "1", "SSDSEG_DW_FWD": "lds", "SSDSEG_DW_BWD": "reg"},
-    "resident-fused": {"SSDSEG_WRES_FORCE": "1", "SSDSEG_PW_FUSED": "1"},
-    "split-k": {"SSDSEG_NO_WRES": "1", "SSDSEG_SPLITK": "1"},
+                "SSDSEG_CONV3_NARROW": "0", "SSDSEG_PW_TILE": "0", "SSDSEG_CONV3_TILE": "0"},
+    "general-reg": {"SSDSEG_NO_WRES": "1", "SSDSEG_DW_FWD": "lds", "SSDSEG_DW_BWD": "reg", "SSDSEG_PW_TILE": "0"},
+    "resident-fused": {"SSDSEG_WRES_FORCE": "1", "SSDSEG_PW_FUSED": "1", "SSDSEG_PW_TILE": "0"},
+    "split-k": {"SSDSEG_NO_WRES": "1", "SSDSEG_SPLITK": "1", "SSDSEG_PW_TILE": "0"},
+    # round 2: the double-buffered tile GEMMs (pw_tile.h) for every shape they take, OCC-limited rowA instantiations for the rest
+    "tile": {"SSDSEG_PW_TILE": "1", "SSDSEG_OCC_ROWS": "0"},
 }
+_FAMILY_VARS = ("SSDSEG_NO_WRES", "SSDSEG_WRES_FORCE", "SSDSEG_PW_FUSED", "SSDSEG_DW_FWD", "SSDSEG_DW_BWD", "SSDSEG_SPLITK", "SSDSEG_CONV3_WGRAD",
+                "SSDSEG_CONV3_NARROW", "SSDSEG_PW_TILE", "SSDSEG_CONV3_TILE", "SSDSEG_OCC_ROWS")
 
 
 def pytest_configure(config):
@@ -51,7 +55,7 @@ def rng():
 
 @pytest.fixture(params=list(KERNEL_FAMILIES))
 def kernel_family(request, monkeypatch):
-    for k in ("SSDSEG_NO_WRES", "SSDSEG_WRES_FORCE", "SSDSEG_PW_FUSED", "SSDSEG_DW_FWD", "SSDSEG_DW_BWD", "SSDSEG_SPLITK", "SSDSEG_CONV3_WGRAD", "SSDSEG_CONV3_NARROW"):
+    for k in _FAMILY_VARS:
         monkeypatch.delenv(k, raising=False)
     for k, v in KERNEL_FAMILIES[request.param].items():
         monkeypatch.setenv(k, v)

@@ -153,6 +153,9 @@ PW_CASES = [
     (66000, 32, 192),    # fused, 6 chunks (largest shape the fused kernel takes)
     (300, 200, 64),      # deep steps (two 32-deep sub-tiles per barrier pair): reduction of 6.25 sub-tiles, both directions
     (9600, 960, 160),    # the 15x20-stage project conv as it runs in the bench
+    (70001, 96, 264),    # >= 65536 rows: the eight-wave tile GEMM (pw_tile.h), ragged last row tile, two 132-column tiles forward
+    (66000, 256, 256),   # eight-wave tile GEMM, one 256-column tile forward / two 128-column tiles backward (the decoder sepconv shape)
+    (300, 72, 40),       # tile GEMM with a reduction that is not a multiple of 32 (72 = 2 steps + 8) and a single ragged column tile
 ]
 
 
