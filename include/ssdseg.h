@@ -309,6 +309,17 @@ int ssdseg_encode_targets(ssdseg_ctx* ctx, const float* anchors_corners, int a, 
                           const int32_t* gt_count, int b, int gmax, int c, float iou_threshold, const float* stds4_host,
                           float* labels, float* boxes, int32_t* match);
 
+/* ---------------------------------------------------------------- compact batch -> engine buffers
+ * DataEncoderDecoder.read_and_encode (datacoder.py:302-347) on the device: the host uploads what the files hold -- uint8 pixels
+ * [b][h][w][3], uint8 class indices [b][h][w], ground-truth rows -- and these two calls (+ ssdseg_encode_targets) produce the
+ * float32 image (tf.cast :327), the float32 one-hot mask [b][h][w][c] (tf.one_hot :332: an index >= c gives an all-zero row) and
+ * the mirrored ground truth of the samples whose flip[n] != 0 (tf.image.flip_left_right :341-342; boxes xmin' = W - xmax,
+ * xmax' = W - xmin :202-203, quirk Q8).  images_u8 or mask_index_u8 may be NULL (only the other is expanded); flip may be NULL. */
+int ssdseg_expand_inputs(ssdseg_ctx* ctx, const uint8_t* images_u8, const uint8_t* mask_index_u8, const uint8_t* flip, float* images_f32,
+                         float* mask_onehot, int b, int h, int w, int c);
+/* gt [b][gmax][5] = (label, xmin, ymin, xmax, ymax), in place, rows g < gt_count[n] of the samples with flip[n] != 0 */
+int ssdseg_flip_gt_boxes(ssdseg_ctx* ctx, float* gt, const int32_t* gt_count, const uint8_t* flip, int b, int gmax, float image_width);
+
 /* ---------------------------------------------------------------- training metrics
  * Per-image values of the three metric factories NB03#cell14 passes to compile(metrics=...); Keras averages them.
  * jaccard_iou_segmentation_masks_metric (metrics.py:35-47): SOFT Jaccard, inter = sum t*p, total = sum(t+p) over pixels,

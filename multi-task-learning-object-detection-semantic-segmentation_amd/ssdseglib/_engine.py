@@ -1383,7 +1383,14 @@ def run_predict(model: K.Model, data) -> List[np.ndarray]:
     return [np.concatenate([c[i] for c in chunks], axis=0) for i in range(len(model.outputs))]
 
 
-def run_train_on_batch(model: K.Model, x, y) -> Dict[str, float]:
+def run_train_on_batch(model: K.Model, x, y=None) -> Dict[str, float]:
+    if _is_compact(x):
+        eng = engine_for(model, len(x), True)
+        ld = _compact_loader(eng, x)
+        ld.stage(x)
+        ld.consume()
+        eng.train_step(optimizer=model._compiled.get("optimizer"))
+        return eng.losses()
     x = np.asarray(x, np.float32)
     eng = engine_for(model, x.shape[0], True)
     eng.train_step(x, y, optimizer=model._compiled.get("optimizer"))
@@ -1434,6 +1441,78 @@ class _BatchStager:
         self.staged = False
 
 
+class _CompactLoader:
+    """A `datacoder.CompactBatch` into the engine's input / target buffers (reference datacoder.py:302-347 == csrc/inputs.hip +
+    ssdseg_encode_targets).  stage(): 39 MB of uint8 pixels / class indices / ground-truth rows go up on the copy stream (under
+    the running step when fit overlaps); consume(): the main stream waits for them and expands -- float32 image, one-hot mask,
+    both mirrored where flagged, mirrored boxes, encoded anchors -- straight into the buffers the step reads."""
+
+    GMAX = 64       # ground-truth rows per image the encode kernel holds in LDS (boxes.hip)
+
+    def __init__(self, eng: "Engine", encoder):
+        self.eng, self.ctx, self.enc = eng, eng.ctx, encoder
+        ctx, b, ins = eng.ctx, eng.batch, eng.input_store
+        ops = {kind: op for _, op, kind in eng._loss_names}
+        self.mask_op, self.det = ops.get("mask"), ops.get("conf") or ops.get("loc")
+        self.img = ctx.empty((b, ins.h, ins.w, 3), np.uint8)
+        self.midx = ctx.empty((b, ins.h, ins.w), np.uint8)
+        self.flip = ctx.empty(b, np.uint8)
+        self.gt = ctx.empty((b, self.GMAX, 5))
+        self.cnt = ctx.empty(b, np.int32)
+        corners = np.stack([encoder.xmin_boxes_default, encoder.ymin_boxes_default, encoder.xmax_boxes_default, encoder.ymax_boxes_default], axis=1)
+        self.anchors = ctx.array(corners.astype(np.float32))
+        if self.det is not None and self.anchors.shape[0] != self.det.y_boxes.shape[1]:
+            raise ValueError(f"encoder has {self.anchors.shape[0]} default boxes, the model's heads {self.det.y_boxes.shape[1]}")
+        self.staged = None
+        self._keep = None
+
+    def stage(self, cb) -> None:
+        b, ins = self.eng.batch, self.eng.input_store
+        if len(cb) != b or cb.images.shape[1:3] != (ins.h, ins.w):
+            raise ValueError(f"compact batch {cb.images.shape} for an engine of batch {b}, {ins.h}x{ins.w}")
+        if max(g.shape[0] for g in cb.ground_truth) > self.GMAX:
+            raise ValueError(f"more than {self.GMAX} ground-truth boxes in one image")
+        gt = np.zeros((b, self.GMAX, 5), np.float32)
+        cnt = np.zeros(b, np.int32)
+        for i, g in enumerate(cb.ground_truth):
+            gt[i, :g.shape[0]] = g
+            cnt[i] = g.shape[0]
+        flip = cb.flip if cb.flip is not None else np.zeros(b, np.uint8)
+        self.ctx.upload_sync()
+        pairs = [(self.img, cb.images), (self.midx, cb.mask_index), (self.gt, gt), (self.cnt, cnt), (self.flip, flip)]
+        for dst, src in pairs:
+            self.ctx.upload_async(dst, src, after_fence=True)
+        self._keep = [src for _, src in pairs]
+        self.staged = bool(flip.any())
+
+    def consume(self) -> None:
+        assert self.staged is not None
+        ctx, b, ins, enc = self.ctx, self.eng.batch, self.eng.input_store, self.enc
+        ctx.upload_join()
+        flip = self.flip if self.staged else None
+        c = self.mask_op.y_true.shape[-1] if self.mask_op is not None else 1
+        ctx.call("ssdseg_expand_inputs", self.img, self.midx if self.mask_op is not None else None, flip, ins.buf,
+                 self.mask_op.y_true if self.mask_op is not None else None, b, ins.h, ins.w, c)
+        if self.det is not None:
+            if flip is not None:
+                ctx.call("ssdseg_flip_gt_boxes", self.gt, self.cnt, flip, b, self.GMAX, float(ins.w))
+            ctx.call("ssdseg_encode_targets", self.anchors, self.anchors.shape[0], self.gt, self.cnt, b, self.GMAX, enc.num_classes,
+                     float(enc.iou_threshold), (C.c_float * 4)(*enc._stds), self.det.y_labels, self.det.y_boxes, None)
+        ctx.upload_fence()                          # from here on the compact staging buffers may be overwritten
+        self.staged = None
+
+
+def _compact_loader(eng: "Engine", cb) -> _CompactLoader:
+    ld = eng.__dict__.get("_compact_loader")
+    if ld is None or ld.enc is not cb.encoder:
+        ld = eng.__dict__["_compact_loader"] = _CompactLoader(eng, cb.encoder)
+    return ld
+
+
+def _is_compact(x) -> bool:
+    return type(x).__name__ == "CompactBatch"
+
+
 class History:
     def __init__(self):
         self.history: Dict[str, List[float]] = {}
@@ -1453,9 +1532,15 @@ def run_fit(model: K.Model, data, epochs=1, validation_data=None, verbose=0) -> 
         staged_for = None      # id of the batch whose upload is in flight, and its stager
         while cur is not None:
             x, y = cur
-            n = int(np.shape(x)[0]) if not isinstance(x, H.DeviceBuffer) else x.shape[0]
+            n = len(x) if _is_compact(x) else (int(np.shape(x)[0]) if not isinstance(x, H.DeviceBuffer) else x.shape[0])
             eng = engine_for(model, n, True)
-            if staged_for is not None and staged_for[0] is cur:
+            if _is_compact(x):
+                ld = _compact_loader(eng, x)
+                if not (staged_for is not None and staged_for[0] is cur):
+                    ld.stage(x)
+                ld.consume()                        # expansion + anchor encoding on the device
+                eng.train_step(optimizer=model._compiled.get("optimizer"))
+            elif staged_for is not None and staged_for[0] is cur:
                 staged_for[1].consume()
                 eng.train_step(optimizer=model._compiled.get("optimizer"))
             else:
@@ -1463,7 +1548,11 @@ def run_fit(model: K.Model, data, epochs=1, validation_data=None, verbose=0) -> 
             # the step is queued; everything below runs on the host while the GPU works on it
             nxt = next(it, None)
             staged_for = None
-            if overlap and nxt is not None and nxt[1] is not None and not isinstance(nxt[0], H.DeviceBuffer) and int(np.shape(nxt[0])[0]) == n:
+            if overlap and nxt is not None and _is_compact(nxt[0]) and _is_compact(x) and len(nxt[0]) == n and nxt[0].encoder is x.encoder:
+                ld = _compact_loader(eng, nxt[0])
+                ld.stage(nxt[0])                    # 39 MB on the copy stream, under the step just queued
+                staged_for = (nxt, ld)
+            elif overlap and nxt is not None and not _is_compact(nxt[0]) and nxt[1] is not None and not isinstance(nxt[0], H.DeviceBuffer) and int(np.shape(nxt[0])[0]) == n:
                 stager = eng.__dict__.setdefault("_stager", None) or _BatchStager(eng)
                 eng._stager = stager
                 if stager.stage(nxt[0], nxt[1]):

@@ -420,7 +420,7 @@ class Model:
         from . import _engine
         return _engine.run_fit(self, data, epochs, validation_data, verbose)
 
-    def train_on_batch(self, x, y):
+    def train_on_batch(self, x, y=None):
         from . import _engine
         return _engine.run_train_on_batch(self, x, y)
 

@@ -116,6 +116,8 @@ _SIGNATURES = {
     "ssdseg_metric_mask_iou": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, C.POINTER(_f), _vp],
     "ssdseg_metric_label_accuracy": [_vp, _vp, _vp, _i, _i, _i, C.POINTER(_f), _vp],
     "ssdseg_metric_box_iou": [_vp, _vp, _vp, _vp, C.POINTER(_f), _i, _i, _vp],
+    "ssdseg_expand_inputs": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
+    "ssdseg_flip_gt_boxes": [_vp, _vp, _vp, _vp, _i, _i, _f],
     "ssdseg_encode_targets": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _f, C.POINTER(_f), _vp, _vp, _vp],
     "ssdseg_decode_boxes": [_vp, _vp, _vp, _i, _i, C.POINTER(_f), _vp],
     "ssdseg_combined_nms": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp],

@@ -120,6 +120,24 @@ class DataEncoderDecoder:
         labels, boxes = self._encode_ground_truth_labels_boxes(path_file_labels_boxes, flip)
         return image, {'output-mask': mask, 'output-labels': labels, 'output-boxes': boxes}
 
+    # ---- compact hand-over: what the files hold goes to the GPU, the expansion happens there (csrc/inputs.hip)
+    def read_compact(self, path_file_image: str, path_file_mask: str, path_file_labels_boxes: str):
+        """one sample as (uint8 image (H, W, 3), uint8 class-index mask (H, W), ground truth (G, 5), flip flag): the inputs of
+        read_and_encode before its float expansion (reference datacoder.py:325-345); `compact_batch` stacks them"""
+        from PIL import Image
+        image = np.asarray(Image.open(path_file_image).convert("RGB"), np.uint8)
+        mask_idx = np.asarray(Image.open(path_file_mask).convert("L"), np.uint8)
+        with open(path_file_labels_boxes, "r", newline="") as f:
+            text = f.read().strip()
+        rows = [r for r in text.replace("\r\n", "\n").split("\n") if r]
+        gt = np.array([[float(v) for v in r.split(",")] for r in rows], np.float32).reshape(-1, 5)
+        flip = bool(self.augmentation_horizontal_flip and self._rng.uniform(0, 1) >= 0.5)
+        return image, mask_idx, gt, flip
+
+    def compact_batch(self, samples) -> "CompactBatch":
+        images, masks, gts, flips = zip(*samples)
+        return CompactBatch(np.stack(images), np.stack(masks), list(gts), np.asarray(flips, np.uint8), self)
+
     # ---- decode of GROUND-TRUTH offsets (reference datacoder.py:349-432)
     def decode_to_centroids(self, offsets_centroids, output_decoded_centroids_separately: bool = False):
         o = np.asarray(offsets_centroids, np.float32)
@@ -141,6 +159,27 @@ class DataEncoderDecoder:
         if output_decoded_corners_separately:
             return xmin, ymin, xmax, ymax
         return np.stack([xmin, ymin, xmax, ymax], axis=1)
+
+
+class CompactBatch:
+    """A training batch as the files hold it: uint8 pixels (B, H, W, 3), uint8 class indices (B, H, W), per-sample ground-truth
+    rows (label, xmin, ymin, xmax, ymax) and flip flags -- 39 MB instead of the 285 MB of float32 tensors at batch 32, 480x640.
+    `Model.fit` / `train_on_batch` accept it in place of (images, targets): float conversion, one-hot, mirroring and the anchor
+    encoding run on the GPU (ssdseg_expand_inputs, ssdseg_flip_gt_boxes, ssdseg_encode_targets)."""
+
+    def __init__(self, images_u8, mask_index_u8, ground_truth, flip, encoder: "DataEncoderDecoder"):
+        self.images = np.ascontiguousarray(images_u8, np.uint8)
+        self.mask_index = np.ascontiguousarray(mask_index_u8, np.uint8)
+        if self.images.ndim != 4 or self.images.shape[-1] != 3 or self.mask_index.shape != self.images.shape[:3]:
+            raise ValueError(f"compact batch: images {self.images.shape} must be (B, H, W, 3) and masks {self.mask_index.shape} (B, H, W)")
+        self.ground_truth = [np.asarray(g, np.float32).reshape(-1, 5) for g in ground_truth]
+        if len(self.ground_truth) != self.images.shape[0]:
+            raise ValueError("compact batch: one ground-truth array per image")
+        self.flip = None if flip is None else np.ascontiguousarray(flip, np.uint8).reshape(self.images.shape[0])
+        self.encoder = encoder
+
+    def __len__(self):
+        return self.images.shape[0]
 
 
 _aug_rng = np.random.default_rng(1993)
@@ -165,22 +204,28 @@ def _hsv_to_rgb(hsv):
     return np.stack([f(5), f(3), f(1)], -1)
 
 
+def _augment_rgb(x, hue_delta, saturation_factor, contrast_factor, brightness_delta):
+    """the four adjustments with GIVEN random draws (tf.image.adjust_hue / adjust_saturation / adjust_contrast /
+    adjust_brightness on float images, then the clip of reference datacoder.py:464)"""
+    x = np.asarray(x, np.float32)
+    hsv = _rgb_to_hsv(x)
+    hsv[..., 0] = (hsv[..., 0] + hue_delta) % 1.0
+    x = _hsv_to_rgb(hsv)
+    hsv = _rgb_to_hsv(x)
+    hsv[..., 1] = np.clip(hsv[..., 1] * saturation_factor, 0.0, 1.0)
+    x = _hsv_to_rgb(hsv)
+    mean = x.mean(axis=(1, 2), keepdims=True)          # per image and channel
+    x = (x - mean) * contrast_factor + mean
+    x = x + brightness_delta
+    return np.clip(x, 0.0, 255.0).astype(np.float32)
+
+
 def augmentation_rgb_channels(image_batch, targets_batch):
     """random hue (+-0.05), saturation (0.95..1.05), contrast (0.9..1.1), brightness (+-0.10) then clip to [0, 255]
     (reference datacoder.py:452-464; the deltas are the [0,1]-scale ones applied to 0..255 images, quirk Q11).
     Host-side input-pipeline step; TF's exact RNG streams are not reproduced."""
-    x = np.asarray(image_batch, np.float32)
-    hsv = _rgb_to_hsv(x)
-    hsv[..., 0] = (hsv[..., 0] + _aug_rng.uniform(-0.05, 0.05)) % 1.0
-    x = _hsv_to_rgb(hsv)
-    hsv = _rgb_to_hsv(x)
-    hsv[..., 1] = np.clip(hsv[..., 1] * _aug_rng.uniform(0.95, 1.05), 0.0, 1.0)
-    x = _hsv_to_rgb(hsv)
-    factor = _aug_rng.uniform(0.90, 1.10)
-    mean = x.mean(axis=(1, 2), keepdims=True)
-    x = (x - mean) * factor + mean
-    x = x + _aug_rng.uniform(-0.10, 0.10)
-    return np.clip(x, 0.0, 255.0).astype(np.float32), targets_batch
+    draws = (_aug_rng.uniform(-0.05, 0.05), _aug_rng.uniform(0.95, 1.05), _aug_rng.uniform(0.90, 1.10), _aug_rng.uniform(-0.10, 0.10))
+    return _augment_rgb(image_batch, *draws), targets_batch
 
 
 def read_image(path_file_image: str) -> np.ndarray:

@@ -528,3 +528,26 @@ def metric_box_iou(y_true, y_pred, cx, cy, w, h, stds):
     inter = wi * hi
     with np.errstate(invalid="ignore", divide="ignore"):
         return (inter / (pw * ph + tw * th - inter + KEPS)).sum(-1) / nb.sum(-1)
+
+
+# ---------------------------------------------------------------------------------------------- input pipeline (datacoder.py:302-347)
+def expand_inputs(images_u8, mask_index_u8, flip, num_classes):
+    """read_and_encode's tensor part on a batch: tf.cast(image, float32) (:327), tf.one_hot(mask, depth) (:332: out-of-range index ->
+    all-zero row), tf.image.flip_left_right of both where flip[n] (:341-342)."""
+    img = np.asarray(images_u8).astype(np.float32)
+    idx = np.asarray(mask_index_u8).astype(np.int64)
+    onehot = (idx[..., None] == np.arange(num_classes)).astype(np.float32)
+    if flip is not None:
+        f = np.asarray(flip).astype(bool)
+        img[f] = img[f][:, :, ::-1]
+        onehot[f] = onehot[f][:, :, ::-1]
+    return img, onehot
+
+
+def flip_gt_boxes(gt, image_width):
+    """horizontal flip of (label, xmin, ymin, xmax, ymax) rows: x -> W - x with W the image WIDTH, not W - 1 (datacoder.py:202-203)"""
+    g = np.asarray(gt, np.float32).reshape(-1, 5)
+    out = g.copy()
+    out[:, 1] = np.float32(image_width) - g[:, 3]
+    out[:, 3] = np.float32(image_width) - g[:, 1]
+    return out

@@ -39,6 +39,16 @@ for mode in ("0", "1"):
     dtf = (time.perf_counter() - t0) / K
     print(f"fit(), SSDSEG_FIT_OVERLAP={mode} ({'next batch staged on the copy stream under the running step' if mode == '1' else 'synchronous hand-over'}): "
           f"{dtf * 1e3:.1f} ms/step = {batch / dtf:.0f} images/sec")
+cb = ssdseglib.datacoder.CompactBatch(x.astype(np.uint8), mask.argmax(-1).astype(np.uint8), [gt[i, :cnt[i]] for i in range(batch)],
+                                      (np.arange(batch) % 2).astype(np.uint8), enc)
+for mode in ("0", "1"):
+    os.environ["SSDSEG_FIT_OVERLAP"] = mode
+    model.fit([cb] * 3, epochs=1)
+    t0 = time.perf_counter()
+    model.fit([cb] * K, epochs=1)
+    dtc = (time.perf_counter() - t0) / K
+    print(f"fit() on COMPACT batches ({(cb.images.nbytes + cb.mask_index.nbytes) / 1e6:.0f} MB uint8 up, expansion + flip + anchor encoding on the "
+          f"device), SSDSEG_FIT_OVERLAP={mode}: {dtc * 1e3:.1f} ms/step = {batch / dtc:.0f} images/sec")
 eng = E.engine_for(model, batch, True)
 t0 = time.perf_counter()
 for _ in range(K):

@@ -189,3 +189,45 @@ def test_bare_pointer_where_a_view_is_expected_is_a_python_error(lib):
     with pytest.raises(C.ArgumentError):
         lib.ssdseg_pwconv_fwd(None, C.c_void_p(0x7f0000000000), 4, None, None, 4, 1, 4, 4, None)
     assert lib.ssdseg_bn_apply(None, C.byref(_hip.view(None)), 4, None, 4, None, 4, 1, 4) == -1001   # reaches C: ctx == NULL -> EINVAL(1)
+
+
+# ---------------------------------------------------------------------------------------------- input pipeline, host side
+def test_oracle_expand_inputs_and_flip_boxes_small_case():
+    """the oracle's restatement of read_and_encode's tensor part (reference datacoder.py:325-345) on a case small enough to write
+    down: cast, one-hot with an out-of-range index, left-right mirror of the flagged sample, x -> W - x for its boxes"""
+    from oracle import np_ops as O
+    img = np.arange(2 * 1 * 3 * 3, dtype=np.uint8).reshape(2, 1, 3, 3)
+    idx = np.array([[[0, 2, 5]], [[1, 1, 0]]], np.uint8)
+    out_img, out_mask = O.expand_inputs(img, idx, np.array([1, 0], np.uint8), 3)
+    assert out_img.dtype == np.float32 and out_mask.dtype == np.float32
+    np.testing.assert_array_equal(out_img[0, 0], [[6, 7, 8], [3, 4, 5], [0, 1, 2]])          # mirrored
+    np.testing.assert_array_equal(out_img[1, 0], [[9, 10, 11], [12, 13, 14], [15, 16, 17]])  # untouched
+    np.testing.assert_array_equal(out_mask[0, 0], [[0, 0, 0], [0, 0, 1], [1, 0, 0]])         # 5 -> zeros, mirrored
+    np.testing.assert_array_equal(out_mask[1, 0], [[0, 1, 0], [0, 1, 0], [1, 0, 0]])
+    gt = np.array([[2, 10, 20, 110, 220], [1, 0, 0, 639, 479]], np.float32)
+    np.testing.assert_array_equal(O.flip_gt_boxes(gt, 640), [[2, 530, 20, 630, 220], [1, 1, 0, 640, 479]])   # W, not W - 1 (quirk Q8)
+    np.testing.assert_array_equal(O.flip_gt_boxes(O.flip_gt_boxes(gt, 640), 640), gt)
+
+
+def test_rgb_augmentation_against_colorsys(rng):
+    """the host-side augmentation_rgb_channels (reference datacoder.py:452-464) with fixed draws vs a per-pixel colorsys
+    restatement of tf.image.adjust_hue / adjust_saturation / adjust_contrast / adjust_brightness + clip"""
+    import colorsys
+    from ssdseglib import datacoder as D
+    x = rng.integers(0, 256, (2, 5, 7, 3)).astype(np.float32)
+    hue, sat, con, bri = 0.04, 1.05, 0.93, 0.08
+    got = D._augment_rgb(x, hue, sat, con, bri)
+    want = np.empty_like(x, dtype=np.float64)
+    for i in np.ndindex(x.shape[:3]):
+        h, s, v = colorsys.rgb_to_hsv(*(x[i].astype(np.float64) / 255.0))
+        r, g, b = colorsys.hsv_to_rgb((h + hue) % 1.0, s, v)
+        h, s, v = colorsys.rgb_to_hsv(r, g, b)
+        want[i] = np.array(colorsys.hsv_to_rgb(h, min(max(s * sat, 0.0), 1.0), v)) * 255.0
+    mean = want.mean(axis=(1, 2), keepdims=True)
+    want = np.clip((want - mean) * con + mean + bri, 0.0, 255.0)
+    np.testing.assert_allclose(got, want, atol=2e-3)
+    # the public wrapper: bounded change, targets untouched, range kept
+    targets = {"output-mask": object()}
+    aug, t = D.augmentation_rgb_channels(x, targets)
+    assert t is targets and aug.dtype == np.float32 and aug.min() >= 0.0 and aug.max() <= 255.0
+    assert np.abs(aug - x).max() < 60.0
