@@ -837,6 +837,7 @@ int rowA_wn(int rows, int cols) { return pick_wn(cols, cdiv(rows, BM)); }
 #include "conv3_wgrad.h"
 #include "conv3_tile.h"
 #include "conv3_wgrad_tile.h"
+#include "conv3_wino.h"
 #include "pw_tile.h"
 
 // ---- tile GEMM of the pointwise convs (pw_tile.h): shape -> (waves, column tile), launch
@@ -1378,6 +1379,46 @@ int conv3t_launch(ssdseg_ctx* ctx, Conv3TArgs a) {
     }
 }
 
+// ---- Winograd F(2x2, 3x3) form (conv3_wino.h).  SSDSEG_CONV3_WINOGRAD=0: the direct halo-tile kernels.
+int conv3_wino_mode() {      // 0 off, 1 forced (any size; parity tests), 2 automatic
+    const char* e = getenv("SSDSEG_CONV3_WINOGRAD");
+    if (!conv3_tile_enabled()) return 0;
+    return e == nullptr || e[0] == '\0' ? 2 : (e[0] == '0' ? 0 : 1);
+}
+// automatic: where the 16 transformed GEMMs fill the chip -- >= 64 output channels, a few hundred pixel tiles
+bool conv3_wino_takes(int n, int h, int w, int cred, int nout) {
+    const int mode = conv3_wino_mode();
+    if (mode == 0 || cred % C3T_KC != 0 || wino_lds_floats(cred) * sizeof(float) > (size_t)160 * 1024) return false;
+    return mode == 1 || (nout >= 64 && (long long)n * cdiv(h, C3T_ROWS) * cdiv(w, C3T_COLS) >= 256);
+}
+
+// a: in / view / out / stats / shape as for conv3t_launch; w = the layer's [3][3][cin][cout] weights; mode 0 forward, 1 input gradient
+int conv3_wino_launch(ssdseg_ctx* ctx, Conv3TArgs a, const float* w, int cin, int cout, int mode) {
+    void* ws;
+    int rc = ssdseg_workspace(ctx, (size_t)16 * cin * cout * sizeof(float), &ws);
+    if (rc) return rc;
+    SSDSEG_LAUNCH(ctx, 4.0 * (9 + 16) * cin * cout, 0.0, conv3_wino_weights_kernel, dim3(cdiv(cout, 32), cdiv(cin, 32)), dim3(256), 0, w, (float*)ws, cin, cout, mode);
+    SSDSEG_LAUNCH_CHECK();
+    a.wt = (const float*)ws;
+    a.tiles_h = cdiv(a.h, C3T_ROWS); a.tiles_w = cdiv(a.w, C3T_COLS); a.ntiles_n = cdiv(a.nout, WINO_NT); a.ncols = WINO_NT;
+    a.in_bytes = (unsigned)((((long long)a.n * a.h * a.w - 1) * a.ldi + a.cred) * 4);
+    a.wt_bytes = (unsigned)((long long)16 * a.nout * a.cred * 4);
+    const size_t lds = wino_lds_floats(a.cred) * sizeof(float);
+    static size_t configured = 0;
+    if (lds > configured) {
+        SSDSEG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    const double m = (double)a.n * a.h * a.w;
+    const double cost_bytes = 4.0 * (m * a.cred + m * a.nout + 9.0 * a.cred * a.nout);   // X + Y + W
+    const double cost_flops = 18.0 * m * a.cred * a.nout;                                // of the convolution (the kernel executes 16/36 of them)
+    const int mtiles = a.n * a.tiles_h * a.tiles_w;
+    const char* kname = ctx->timing ? ssdseg_intern(mode ? "conv3_wino_kernel [bwd_data]" : "conv3_wino_kernel [fwd]") : "";
+    SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, conv3_wino_kernel, dim3((unsigned)(mtiles * a.ntiles_n)), dim3(C3T_THREADS), lds, a);
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1803,6 +1844,14 @@ int ssdseg_conv3x3_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const fl
         if (rc) return rc;
         SSDSEG_LAUNCH(ctx, 8.0 * 9 * cin * cout, 0.0, conv3_transpose_w_kernel, dim3(cdiv(cout, 32), cdiv(cin, 32), 9), dim3(256), 0, w, (float*)ws, cin, cout);
         SSDSEG_LAUNCH_CHECK();
+        if (conv3_wino_takes(n, h, wdt, cin, cout)) {
+            Conv3TArgs t{};
+            t.in = in->x; t.cs = in->scale; t.ct = in->shift; t.act = in->act; t.ldi = ldx;
+            t.out = y; t.ldo = cout; t.accumulate = 0;
+            t.stats = stats;
+            t.n = n; t.h = h; t.w = wdt; t.cred = cin; t.nout = cout; t.flip = 0;
+            return conv3_wino_launch(ctx, t, w, cin, cout, 0);
+        }
         Conv3TArgs t{};
         t.in = in->x; t.cs = in->scale; t.ct = in->shift; t.act = in->act; t.ldi = ldx;
         t.wt = (const float*)ws;
@@ -1858,6 +1907,13 @@ int ssdseg_conv3x3_bwd_data(ssdseg_ctx* ctx, const ssdseg_gview* dy, const float
         // dx[p][c] = sum_{tap, n} dy[p - d(tap)][n] W[tap][c][n]: the forward loop over the mirrored taps; W's native layout already has
         // the reduction channel (n) contiguous.  (A BatchNorm gradient view is materialised by the caller first: nine taps would
         // each re-form it -- ssdseg_gview_materialize.)
+        if (conv3_wino_takes(n, h, wdt, cout, cin)) {
+            Conv3TArgs t{};
+            t.in = dy->g; t.act = SSDSEG_ACT_NONE; t.ldi = cout;
+            t.out = dx; t.ldo = ldx; t.accumulate = accumulate;
+            t.n = n; t.h = h; t.w = wdt; t.cred = cout; t.nout = cin; t.flip = 0;
+            return conv3_wino_launch(ctx, t, w, cin, cout, 1);
+        }
         Conv3TArgs t{};
         t.in = dy->g; t.act = SSDSEG_ACT_NONE; t.ldi = cout;
         t.wt = w;

@@ -26,7 +26,7 @@ KERNEL_FAMILIES = {
     "tile": {"SSDSEG_PW_TILE": "1", "SSDSEG_OCC_ROWS": "0"},
 }
 _FAMILY_VARS = ("SSDSEG_NO_WRES", "SSDSEG_WRES_FORCE", "SSDSEG_PW_FUSED", "SSDSEG_DW_FWD", "SSDSEG_DW_BWD", "SSDSEG_SPLITK", "SSDSEG_CONV3_WGRAD",
-                "SSDSEG_CONV3_NARROW", "SSDSEG_PW_TILE", "SSDSEG_CONV3_TILE", "SSDSEG_OCC_ROWS")
+                "SSDSEG_CONV3_NARROW", "SSDSEG_PW_TILE", "SSDSEG_CONV3_TILE", "SSDSEG_CONV3_WINOGRAD", "SSDSEG_OCC_ROWS")
 
 
 def pytest_configure(config):

@@ -43,14 +43,16 @@ def gview_inputs(rng, shape, act):
                                             (2, 17, 33, 40, 200),   # odd number of 8-channel steps; two 100-column tiles of a 128-wide block
                                             (1, 8, 32, 12, 16)])    # cin not a multiple of 8: the implicit-GEMM forward, halo-tile backward
 # kernel family: "narrow" = cout <= 8 as tap-expanded pointwise GEMMs (default for those shapes); "tile" = the halo-tile kernels
-# (conv3_tile.h, default for everything else); "gemm" = the implicit-GEMM kernels
-@pytest.mark.parametrize("family", ["narrow", "tile", "gemm"])
+# (conv3_tile.h); "wino" = the Winograd F(2x2, 3x3) kernels forced at every size (conv3_wino.h, default for the large layers: same
+# tolerance -- its transforms are additions and halvings); "gemm" = the implicit-GEMM kernels
+@pytest.mark.parametrize("family", ["narrow", "tile", "wino", "gemm"])
 def test_conv3x3_fwd_bwd(ctx, rng, monkeypatch, n, h, w, cin, cout, family):
     from ssdseglib import _hip as H
     if family == "narrow" and cout > 8:
         pytest.skip("tap-expanded form only for cout <= 8")
     monkeypatch.setenv("SSDSEG_CONV3_NARROW", "1" if family == "narrow" else "0")
     monkeypatch.setenv("SSDSEG_CONV3_TILE", "0" if family == "gemm" else "1")
+    monkeypatch.setenv("SSDSEG_CONV3_WINOGRAD", "1" if family == "wino" else "0")
     act = O.ACT_RELU6
     x, sc, sh, a = view_inputs(rng, (n, h, w, cin), act)
     wgt = (rng.normal(0, 1, (3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
