@@ -10,31 +10,37 @@
 // error is ~2x that of the direct fp32 sum (7e-7 vs 3e-7 of the output scale at K = 304; tests hold it to 1e-5).
 //
 // One block = eight waves = an 8-row x 32-column patch of output pixels (4 x 16 = 64 Winograd tiles) x 64 output channels x
-// all 16 positions: 64 x 64 x 16 accumulators = 128 registers per lane; wave v owns positions 2v, 2v+1.  Per step of 8 input
-// channels a block
-//   stages   the (8+2) x (32+2) input halo (view applied while staging, zero padding after the view) and the 16 x 64 x 8
-//            slice of the transformed weights U = G w G^T (pre-computed per launch by conv3_wino_weights_kernel) -> LDS;
-//   forms    V = B^T d B for its 64 tiles x 8 channels: thread (a, 4-channel quad, tile) reads the two patch rows that row a
-//            of B^T combines (8 ds_read_b128), 32 additions, 4 ds_write_b128 -- the transformed input never exists in HBM;
-//   runs     per wave 2 positions x (2 x 2) 32x32 tiles x 4 MFMAs on 16-byte fragments (channel pairs (j, 4+j) as in
-//            conv3_tile.h): 8 ds_read_b128 per 32 v_mfma_f32_32x32x2_f32.
-// Three-deep software pipeline, ONE barrier per step: in iteration s the global loads of patch s+2 / weights s+1 are in
-// flight, patch s+1 (staged in iteration s-1) is transformed into V[(s+1)&1], the MFMAs consume V[s&1], U[s&1].
-// Epilogue: the accumulators go through LDS once (two halves of 32 output channels), each thread applies A^T . A to the 16
-// positions of its (tile, channel) pairs, writes the 2x2 outputs and -- forward -- accumulates the BatchNorm partial sums of
-// the block (one partial row per pixel tile, fixed order, no atomics), exactly like the halo-tile kernel.
+// all 16 positions: 64 x 64 x 16 accumulators = 128 registers per lane.  Wave = (row a of the 4x4 position grid, half of the
+// tiles); it owns positions 4a .. 4a+3 for its 32 tiles.  Per step of 8 input channels
+//   the block stages  the (8+2) x (32+2) input halo (view applied while staging, zero padding after the view) and the 16 x 64 x 8
+//                     slice of the transformed weights U = G w G^T (pre-computed per launch by conv3_wino_weights_kernel) in LDS;
+//   each lane forms   row a of V = B^T d B for ITS tile and 4-channel quad from the two patch rows that row a of B^T combines:
+//                     8 ds_read_b128, 32 additions -- and those four float4 ARE the A fragments (row = tile, 16-byte fragments,
+//                     channel pairs (j, 4+j) as in conv3_tile.h) of the positions the wave owns: the transformed input exists
+//                     neither in HBM nor in LDS, a wave multiplies what it transformed;
+//   each wave runs    4 positions x 2 column blocks x 4 MFMAs against 8 ds_read_b128 of U.
+// Software pipeline, ONE barrier per step: in iteration s the global loads of patch s+2 / weights s+1 are in flight, patch s+1
+// (staged in iteration s-1) is transformed into next step's A registers in the shadow of the MFMAs of step s.
+// Epilogue: each wave applies the column half of A^T . A in registers (it holds all four b of its row a), the row half sums over
+// the four a through LDS once; the threads write the 2x2 outputs and -- forward -- the BatchNorm partial sums of the block (one
+// partial row per pixel tile, fixed order, no atomics), exactly like the halo-tile kernel.
 //
-//   forward:   in = x (raw + view), U[k][n][c] from w[i][j][c][n]
-//   backward:  in = dy,             U[k][c][n] from w[2-i][2-j][c][n]   (the mirrored, transposed filter)
+//   forward:   in = x (raw + view), U from w[i][j][c][n], reduction over c
+//   backward:  in = dy,             U from w[2-i][2-j][c][n] (the mirrored, transposed filter), reduction over n
 #pragma once
 
 constexpr int WINO_NT = 64;                          // output channels per block
 constexpr int WINO_TILES = 64;                       // 2x2 output tiles per block (4 rows x 16 columns of tiles)
-constexpr int WINO_V_F = 16 * WINO_TILES * C3T_KC;   // floats of one V buffer  [k][tile][8]
-constexpr int WINO_U_F = 16 * WINO_NT * C3T_KC;      // floats of one U buffer  [k][n][8]
-constexpr int WINO_MS_LD = 33;                       // epilogue: M rows of 32 channels, padded (the two lane halves sit 4 tiles apart)
-constexpr size_t wino_lds_floats(int cred) { return 2 * (size_t)(C3T_PATCH_F + WINO_V_F + WINO_U_F) + 2 * (size_t)(cred + 16); }
-static_assert(16 * WINO_TILES * WINO_MS_LD + 2 * 2 * 16 * 32 <= 2 * (C3T_PATCH_F + WINO_V_F + WINO_U_F), "epilogue staging fits the operand buffers");
+constexpr int WINO_PIXP = 344;                       // patch pixels per 4-channel plane, padded: the two planes sit 8 sixteen-byte slots apart
+constexpr int WINO_RAW_F = 2 * WINO_PIXP * 4;        // floats of one patch buffer  [quad][pixel][4]
+constexpr int WINO_U_F = 16 * WINO_NT * C3T_KC;      // floats of one U buffer      [k][n][8]
+constexpr int WINO_MS_LD = 33;                       // epilogue rows of 32 channels, padded (the two lane halves sit 4 tiles apart)
+constexpr int WINO_MS_F = 4 * 2 * WINO_TILES * 2 * WINO_MS_LD;     // [a][j][tile][cb][33]
+constexpr int WINO_RED_F = 2 * 2 * 8 * 32;           // [cb][sum | sumsq][tile group][32]
+constexpr size_t wino_lds_floats(int cred) {
+    const size_t loop = 2 * (size_t)(WINO_RAW_F + WINO_U_F) + 2 * (size_t)(cred + 16), epi = (size_t)WINO_MS_F + WINO_RED_F;
+    return loop > epi ? loop : epi;
+}
 
 __global__ void __launch_bounds__(C3T_THREADS, 2) conv3_wino_kernel(Conv3TArgs p) {
     constexpr int PSLOTS = C3T_PIX * 2;                // float4 slots of a patch (680)
@@ -43,7 +49,7 @@ __global__ void __launch_bounds__(C3T_THREADS, 2) conv3_wino_kernel(Conv3TArgs p
     constexpr int UQ = USLOTS / C3T_THREADS;
     extern __shared__ float smem[];
     // buffer offsets (floats from smem; integers, so that every access stays a DS instruction through the buffer swaps)
-    constexpr int RAW0 = 0, RAW1 = C3T_PATCH_F, V0 = 2 * C3T_PATCH_F, V1 = V0 + WINO_V_F, U0 = V1 + WINO_V_F, U1 = U0 + WINO_U_F;
+    constexpr int RAW0 = 0, RAW1 = WINO_RAW_F, U0 = 2 * WINO_RAW_F, U1 = U0 + WINO_U_F;
     float* coef = smem + U1 + WINO_U_F;                // [2][cred + 16]: scale, shift of the input view (+ spare steps)
     const int cld = p.cred + 16;
 
@@ -68,10 +74,16 @@ __global__ void __launch_bounds__(C3T_THREADS, 2) conv3_wino_kernel(Conv3TArgs p
         coef[cld + i] = (affine && i < p.cred) ? p.ct[i] : 0.f;
     }
 
+    // patch pixel (row, col) of plane `quad` -> LDS float offset.  Columns 16..31 swap places pairwise: the sixteen lanes of a
+    // transform read sit two pixels apart, so lanes c and c + 16 would share a 16-byte slot; with the swap one of them moves to
+    // the neighbouring (odd / even) slot and every group of sixteen lanes covers sixteen distinct slots.
+    auto raw_off = [](int prow, int pcol, int quad) { return (quad * WINO_PIXP + prow * C3T_PW + (pcol ^ ((pcol >> 4) & 1))) * 4; };
+
     // ---- staging slots (fixed per thread): raw buffer loads, 32-bit offsets, hardware range check (offset 2^31 -> zeros)
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, p.wt_bytes, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
+    const int npad = p.ntiles_n * WINO_NT;
     unsigned pgo[PQ], ugo[UQ];
     int plo[PQ], ulo[UQ];
     unsigned inimg = 0;      // bit q: patch slot q is an image pixel (else zero padding -- NOT act(shift))
@@ -83,7 +95,7 @@ __global__ void __launch_bounds__(C3T_THREADS, 2) conv3_wino_kernel(Conv3TArgs p
         const int gh = h0 - 1 + prow, gw = w0 - 1 + pcol;
         const bool ok = slot < PSLOTS && gh >= 0 && gh < p.h && gw >= 0 && gw < p.w;
         pgo[q] = ok ? (unsigned)(((((long long)img * p.h + gh) * p.w + gw) * p.ldi + 4 * chunk) * 4) : OOB;
-        plo[q] = slot < PSLOTS ? pix * C3T_KC + 4 * (chunk ^ ((pix >> 3) & 1)) : -1;
+        plo[q] = slot < PSLOTS ? raw_off(prow, pcol, chunk) : -1;
         inimg |= (ok ? 1u : 0u) << q;
     }
 #pragma unroll
@@ -92,10 +104,11 @@ __global__ void __launch_bounds__(C3T_THREADS, 2) conv3_wino_kernel(Conv3TArgs p
         const int chunk = slot & 1, rowi = slot >> 1;          // rowi = k * 64 + nn
         const int nn = rowi & (WINO_NT - 1), k = rowi / WINO_NT;
         const bool ok = n0 + nn < p.nout;
-        ugo[q] = ok ? (unsigned)((((long long)k * p.nout + n0 + nn) * p.cred + 4 * chunk) * 4) : OOB;
+        ugo[q] = ok ? (unsigned)((((long long)k * npad + n0 + nn) * C3T_KC + 4 * chunk) * 4) : OOB;      // + step * ustep bytes
         ulo[q] = rowi * C3T_KC + 4 * (chunk ^ ((nn >> 3) & 1));
     }
     const int pchunk = t & 1;
+    const int ustep = 16 * npad * C3T_KC * 4;          // bytes of one step of U[step][k][npad][8]
 
     float4 preg[PQ], ureg[UQ];
     auto issue_raw = [&](int s) {
@@ -104,7 +117,7 @@ __global__ void __launch_bounds__(C3T_THREADS, 2) conv3_wino_kernel(Conv3TArgs p
         for (int q = 0; q < PQ; ++q) preg[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rin, pgo[q], soff, 0));
     };
     auto issue_u = [&](int s) {
-        const int soff = s * C3T_KC * 4;
+        const int soff = s * ustep;
 #pragma unroll
         for (int q = 0; q < UQ; ++q) ureg[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rwt, ugo[q], soff, 0));
     };
@@ -123,75 +136,66 @@ __global__ void __launch_bounds__(C3T_THREADS, 2) conv3_wino_kernel(Conv3TArgs p
         for (int q = 0; q < UQ; ++q) st4(buf + ulo[q], ureg[q]);
     };
 
-    // ---- input transform: thread = (row a of B^T: wave >> 1, 4-channel quad: wave & 1, tile: lane).
+    // ---- roles.  Wave = (row a of the 4x4 transformed tile: wave >> 1, half of the block's tiles: wave & 1); lane = (tile of that
+    // half: lane & 31, 4-channel quad: lane >> 5).  The lane forms V[a][0..3] = (B^T d B)[a][.] of ITS tile and quad in registers
     //   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]:  row a combines patch rows (i0, i1) = (0,2) (1,2) (2,1) (1,3), sign - + - -
-    const int ta = wave >> 1, tq = wave & 1;
-    const int ttr = lane >> 4, ttc = lane & 15;
+    // and that float4 IS the A fragment of the 16-byte-fragment MFMA scheme for position k = 4a + b (row = tile, lanes 0-31 channels
+    // 0-3, lanes 32-63 channels 4-7): the transformed input never touches LDS, the wave multiplies what it transformed.
+    const int ta = wave >> 1, rbk = wave & 1;
+    const int tile = rbk * 32 + li, ttr = tile >> 4, ttc = tile & 15;
     const int ti0 = ta == 0 ? 0 : (ta == 2 ? 2 : 1);
     const int ti1 = ta == 0 ? 2 : (ta == 1 ? 2 : (ta == 2 ? 1 : 3));
     const float tsgn = ta == 1 ? 1.f : -1.f;
     int tro[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int px0 = (2 * ttr + ti0) * C3T_PW + 2 * ttc + j, px1 = (2 * ttr + ti1) * C3T_PW + 2 * ttc + j;
-        tro[j] = px0 * C3T_KC + 4 * (tq ^ ((px0 >> 3) & 1));
-        tro[4 + j] = px1 * C3T_KC + 4 * (tq ^ ((px1 >> 3) & 1));
+        tro[j] = raw_off(2 * ttr + ti0, 2 * ttc + j, hh);
+        tro[4 + j] = raw_off(2 * ttr + ti1, 2 * ttc + j, hh);
     }
-    const int two = (4 * ta * WINO_TILES + lane) * C3T_KC + 4 * (tq ^ ((lane >> 3) & 1));       // + b * 64 * 8 per column position
-    auto transform = [&](int roff, int voff) {
+    auto transform_load = [&](int roff, float4* r) {
         const float* raw = smem + roff;
-        float* v = smem + voff;
-        float4 r[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float4 d0 = ld4(raw + tro[j]), d1 = ld4(raw + tro[4 + j]);
             r[j] = make_float4(fmaf(tsgn, d1.x, d0.x), fmaf(tsgn, d1.y, d0.y), fmaf(tsgn, d1.z, d0.z), fmaf(tsgn, d1.w, d0.w));
         }
-        st4(v + two + 0 * WINO_TILES * C3T_KC, make_float4(r[0].x - r[2].x, r[0].y - r[2].y, r[0].z - r[2].z, r[0].w - r[2].w));
-        st4(v + two + 1 * WINO_TILES * C3T_KC, make_float4(r[1].x + r[2].x, r[1].y + r[2].y, r[1].z + r[2].z, r[1].w + r[2].w));
-        st4(v + two + 2 * WINO_TILES * C3T_KC, make_float4(r[2].x - r[1].x, r[2].y - r[1].y, r[2].z - r[1].z, r[2].w - r[1].w));
-        st4(v + two + 3 * WINO_TILES * C3T_KC, make_float4(r[1].x - r[3].x, r[1].y - r[3].y, r[1].z - r[3].z, r[1].w - r[3].w));
+    };
+    auto transform_finish = [&](const float4* r, float4* v) {
+        v[0] = make_float4(r[0].x - r[2].x, r[0].y - r[2].y, r[0].z - r[2].z, r[0].w - r[2].w);
+        v[1] = make_float4(r[1].x + r[2].x, r[1].y + r[2].y, r[1].z + r[2].z, r[1].w + r[2].w);
+        v[2] = make_float4(r[2].x - r[1].x, r[2].y - r[1].y, r[2].z - r[1].z, r[2].w - r[1].w);
+        v[3] = make_float4(r[1].x - r[3].x, r[1].y - r[3].y, r[1].z - r[3].z, r[1].w - r[3].w);
     };
 
-    // ---- MFMA fragments: wave owns positions k = 2*wave + kk; rows = tiles (rb * 32 + li), columns = channels (cb * 32 + li)
+    // ---- MFMAs: positions k = 4a + b, rows = the wave's 32 tiles, columns = output channels cb * 32 + li
     const int foff = li * C3T_KC + 4 * (hh ^ ((li >> 3) & 1));
-    f32x16 acc[2][2][2];
+    f32x16 acc[4][2];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+    for (int b = 0; b < 4; ++b)
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+        for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[kk][rb][cb][e] = 0.f;
+            for (int e = 0; e < 16; ++e) acc[b][cb][e] = 0.f;
 
-    auto compute = [&](int voff, int uoff) {
-        const float* v = smem + voff;
-        const float* u = smem + uoff;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int k = 2 * wave + kk;
-            const float4 a0 = ld4(v + (k * WINO_TILES + 0) * C3T_KC + foff), a1 = ld4(v + (k * WINO_TILES + 32) * C3T_KC + foff);
-            const float4 b0 = ld4(u + (k * WINO_NT + 0) * C3T_KC + foff), b1 = ld4(u + (k * WINO_NT + 32) * C3T_KC + foff);
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
-                const float4 a = rb ? a1 : a0;
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb) {
-                    const float4 b = cb ? b1 : b0;
-                    acc[kk][rb][cb] = mfma32(a.x, b.x, acc[kk][rb][cb]);
-                    acc[kk][rb][cb] = mfma32(a.y, b.y, acc[kk][rb][cb]);
-                    acc[kk][rb][cb] = mfma32(a.z, b.z, acc[kk][rb][cb]);
-                    acc[kk][rb][cb] = mfma32(a.w, b.w, acc[kk][rb][cb]);
-                }
-            }
-        }
+    auto compute = [&](const float4* av, int uoff, int b) {
+        const float* u = smem + uoff + (4 * ta + b) * WINO_NT * C3T_KC + foff;
+        const float4 b0 = ld4(u), b1 = ld4(u + 32 * C3T_KC);
+        const float4 a = av[b];
+        acc[b][0] = mfma32(a.x, b0.x, acc[b][0]);
+        acc[b][1] = mfma32(a.x, b1.x, acc[b][1]);
+        acc[b][0] = mfma32(a.y, b0.y, acc[b][0]);
+        acc[b][1] = mfma32(a.y, b1.y, acc[b][1]);
+        acc[b][0] = mfma32(a.z, b0.z, acc[b][0]);
+        acc[b][1] = mfma32(a.z, b1.z, acc[b][1]);
+        acc[b][0] = mfma32(a.w, b0.w, acc[b][0]);
+        acc[b][1] = mfma32(a.w, b1.w, acc[b][1]);
     };
 
-    // ---- pipeline.  Invariant at the top of iteration s: V[s&1] = B^T d B of step s, U[s&1] = weights of step s, raw[(s+1)&1] =
-    // patch of step s+1, all visible.  Loads / commits / transforms past the last step run on harmless data (range-checked
-    // loads, spare coefficient entries) into buffers nobody reads: no conditionals around memory operations in the loop.
+    // ---- pipeline.  Invariant at the top of iteration s: acur = transformed input of step s (registers), U[s&1] = weights of step
+    // s, raw[(s+1)&1] = patch of step s+1, all visible.  Loads / commits / transforms past the last step run on harmless data
+    // (range-checked loads, spare coefficient entries) into buffers nobody reads: no conditionals around memory operations.
     const int S = p.cred / C3T_KC;
+    float4 tr[4], acur[4], anxt[4];
     issue_raw(0);
     issue_u(0);
     __syncthreads();            // coef[] visible
@@ -199,96 +203,100 @@ __global__ void __launch_bounds__(C3T_THREADS, 2) conv3_wino_kernel(Conv3TArgs p
     commit_u(U0);
     issue_raw(1);
     __syncthreads();
-    transform(RAW0, V0);
+    transform_load(RAW0, tr);
+    transform_finish(tr, acur);
     commit_raw(1, RAW1);
     __syncthreads();
-    int rcur = RAW0, rnxt = RAW1, vcur = V0, vnxt = V1, ucur = U0, unxt = U1;
+    int rcur = RAW0, rnxt = RAW1, ucur = U0, unxt = U1;
     for (int s = 0; s < S; ++s) {
         issue_raw(s + 2);
         issue_u(s + 1);
-        transform(rnxt, vnxt);          // step s+1
-        compute(vcur, ucur);            // step s
-        commit_raw(s + 2, rcur);        // last read by transform(s), one barrier ago
+        transform_load(rnxt, tr);       // step s+1: the patch reads go out ahead of the first MFMA block ...
+        __builtin_amdgcn_sched_barrier(0);
+        compute(acur, ucur, 0);         // step s
+        __builtin_amdgcn_sched_barrier(0);
+        transform_finish(tr, anxt);     // ... the additions run in its shadow
+        __builtin_amdgcn_sched_barrier(0);
+        compute(acur, ucur, 1);
+        compute(acur, ucur, 2);
+        compute(acur, ucur, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        commit_raw(s + 2, rcur);        // last read by the transform of iteration s-1, one barrier ago
         commit_u(unxt);                 // last read by compute(s-1)
         __syncthreads();
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acur[b] = anxt[b];
         int x;
         x = rcur; rcur = rnxt; rnxt = x;
-        x = vcur; vcur = vnxt; vnxt = x;
         x = ucur; ucur = unxt; unxt = x;
     }
 
     // ---- epilogue.  C/D layout of a 32x32 accumulator: column = lane & 31 (output channel), row = (e & 3) + 8 * (e >> 2) + 4 * hh (tile).
-    //   A^T = [1 1 1 0; 0 1 -1 -1]:  y[i][j] = sum_ab A^T[i][a] m[a][b] A^T[j][b]
-    float* ms = smem;                                             // [16][64 tiles][33]
-    float* red = smem + 16 * WINO_TILES * WINO_MS_LD;             // [2 halves][2][16 groups][32]
-    const int ecol = t & 31, eg = t >> 5;                         // thread = (channel of the half, tile group): tiles eg, eg+16, eg+32, eg+48
+    //   A^T = [1 1 1 0; 0 1 -1 -1]:  y[i][j] = sum_ab A^T[i][a] m[a][b] A^T[j][b].  The wave holds all four b of its row a: the
+    //   column half of the transform happens in registers (c_j = sum_b A^T[j][b] m[a][b]), the sum over a goes through LDS once.
+    float* ms = smem;                                             // [a][j][tile][cb][33]
+    float* red = smem + WINO_MS_F;
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
+    for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        for (int e = 0; e < 16; ++e) {
+            const int tl = rbk * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+            const float m0 = acc[0][cb][e], m1 = acc[1][cb][e], m2 = acc[2][cb][e], m3 = acc[3][cb][e];
+            ms[(((ta * 2 + 0) * WINO_TILES + tl) * 2 + cb) * WINO_MS_LD + li] = m0 + m1 + m2;
+            ms[(((ta * 2 + 1) * WINO_TILES + tl) * 2 + cb) * WINO_MS_LD + li] = m1 - m2 - m3;
+        }
+    __syncthreads();
+    const int ecol = t & 31, ecb = (t >> 5) & 1, eg = t >> 6;     // thread = (channel: ecb * 32 + ecol, tile group: tiles eg, eg + 8, ...)
+    const int jl = ecb * 32 + ecol, j = n0 + jl;
+    const bool jok = j < p.nout;
+    float ssum = 0.f, ssq = 0.f;
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
+    for (int r = 0; r < 8; ++r) {
+        const int tl = eg + 8 * r;
+        const int tr2 = tl >> 4, tc2 = tl & 15;
+        float c[4][2];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int tile = rb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                    ms[((2 * wave + kk) * WINO_TILES + tile) * WINO_MS_LD + li] = acc[kk][rb][cb][e];
-                }
-        __syncthreads();
-        const int jl = cb * 32 + ecol, j = n0 + jl;
-        const bool jok = j < p.nout;
-        float ssum = 0.f, ssq = 0.f;
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int tile = eg + 16 * r;
-            const int tr = tile >> 4, tc = tile & 15;
-            float m[16];
+            for (int jj = 0; jj < 2; ++jj) c[a][jj] = ms[(((a * 2 + jj) * WINO_TILES + tl) * 2 + ecb) * WINO_MS_LD + ecol];
+        const float yv[4] = {c[0][0] + c[1][0] + c[2][0], c[0][1] + c[1][1] + c[2][1], c[1][0] - c[2][0] - c[3][0], c[1][1] - c[2][1] - c[3][1]};
+        const int oh = h0 + 2 * tr2, ow = w0 + 2 * tc2;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) m[k] = ms[(k * WINO_TILES + tile) * WINO_MS_LD + ecol];
-            float c0[4], c1[4];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                c0[b] = m[0 + b] + m[4 + b] + m[8 + b];
-                c1[b] = m[4 + b] - m[8 + b] - m[12 + b];
-            }
-            const float y00 = c0[0] + c0[1] + c0[2], y01 = c0[1] - c0[2] - c0[3];
-            const float y10 = c1[0] + c1[1] + c1[2], y11 = c1[1] - c1[2] - c1[3];
-            const int oh = h0 + 2 * tr, ow = w0 + 2 * tc;
-            const float yv[4] = {y00, y01, y10, y11};
-#pragma unroll
-            for (int o = 0; o < 4; ++o) {
-                const int hh2 = oh + (o >> 1), ww2 = ow + (o & 1);
-                if (jok && hh2 < p.h && ww2 < p.w) {
-                    float* dst = p.out + (((long long)img * p.h + hh2) * p.w + ww2) * p.ldo + j;
-                    float val = yv[o];
-                    if (p.accumulate) val += *dst;
-                    *dst = val;
-                    ssum += yv[o];
-                    ssq = fmaf(yv[o], yv[o], ssq);
-                }
+        for (int o = 0; o < 4; ++o) {
+            const int hh2 = oh + (o >> 1), ww2 = ow + (o & 1);
+            if (jok && hh2 < p.h && ww2 < p.w) {
+                float* dst = p.out + (((long long)img * p.h + hh2) * p.w + ww2) * p.ldo + j;
+                float val = yv[o];
+                if (p.accumulate) val += *dst;
+                *dst = val;
+                ssum += yv[o];
+                ssq = fmaf(yv[o], yv[o], ssq);
             }
         }
-        if (p.stats != nullptr) {
-            red[((cb * 2 + 0) * 16 + eg) * 32 + ecol] = ssum;
-            red[((cb * 2 + 1) * 16 + eg) * 32 + ecol] = ssq;
-        }
-        __syncthreads();          // ms is rewritten by the next half; red complete after the second
     }
-    if (p.stats != nullptr && t < 2 * WINO_NT) {
-        const int which = t / WINO_NT, jl = t - which * WINO_NT;
-        const int cb = jl >> 5, col = jl & 31, j = n0 + jl;
-        if (j < p.nout) {
-            float v = 0.f;
+    if (p.stats != nullptr) {
+        red[((ecb * 2 + 0) * 8 + eg) * 32 + ecol] = ssum;
+        red[((ecb * 2 + 1) * 8 + eg) * 32 + ecol] = ssq;
+        __syncthreads();
+        if (t < 2 * WINO_NT) {
+            const int which = t / WINO_NT, jl2 = t - which * WINO_NT;
+            const int cb = jl2 >> 5, col = jl2 & 31, j2 = n0 + jl2;
+            if (j2 < p.nout) {
+                float v = 0.f;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) v += red[((cb * 2 + which) * 16 + g) * 32 + col];
-            p.stats[((long long)mtile * 2 + which) * p.nout + j] = v;
+                for (int g = 0; g < 8; ++g) v += red[((cb * 2 + which) * 8 + g) * 32 + col];
+                p.stats[((long long)mtile * 2 + which) * p.nout + j2] = v;
+            }
         }
     }
 }
 
-// U = G w G^T per (input channel, output channel) pair, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]; written with the reduction
-// channel contiguous.  mode 0 (forward): U[k][n][c] from w[i][j][c][n];  mode 1 (input gradient): U[k][c][n] from
-// w[2-i][2-j][c][n].  One 32 x 32 (c, n) tile per block through LDS, so reads (n contiguous) and writes are both coalesced.
+// U = G w G^T per (input channel, output channel) pair, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], stored in the order the conv kernel
+// streams it: U[step = r / 8][k][o (padded to whole 64-channel blocks)][r % 8], r the reduction channel, o the output channel -- a
+// block's slice of one step is 16 contiguous 2 KB pieces.  mode 0 (forward): r = c, o = n, from w[i][j][c][n];  mode 1 (input
+// gradient): r = n, o = c, from w[2-i][2-j][c][n].  One 32 x 32 (c, n) tile per block through LDS.
 __global__ void __launch_bounds__(256) conv3_wino_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int cin, int cout, int mode) {
+    const int opad = (mode == 0 ? (cout + WINO_NT - 1) / WINO_NT : (cin + WINO_NT - 1) / WINO_NT) * WINO_NT;
     __shared__ float tile[9][32][33];
     const int c0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
@@ -322,8 +330,8 @@ __global__ void __launch_bounds__(256) conv3_wino_weights_kernel(const float* __
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const int k = 4 * a + b;
-                if (mode == 0) u[((long long)k * cout + n) * cin + c] = o[b];
-                else u[((long long)k * cin + c) * cout + n] = o[b];
+                const int rr = mode == 0 ? c : n, oo = mode == 0 ? n : c;
+                u[((((long long)(rr >> 3) * 16 + k) * opad + oo) << 3) + (rr & 7)] = o[b];
             }
         }
     }

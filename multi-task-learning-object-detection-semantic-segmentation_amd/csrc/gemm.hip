@@ -1395,14 +1395,16 @@ bool conv3_wino_takes(int n, int h, int w, int cred, int nout) {
 // a: in / view / out / stats / shape as for conv3t_launch; w = the layer's [3][3][cin][cout] weights; mode 0 forward, 1 input gradient
 int conv3_wino_launch(ssdseg_ctx* ctx, Conv3TArgs a, const float* w, int cin, int cout, int mode) {
     void* ws;
-    int rc = ssdseg_workspace(ctx, (size_t)16 * cin * cout * sizeof(float), &ws);
+    const int npad = cdiv(a.nout, WINO_NT) * WINO_NT;
+    const size_t ubytes = (size_t)16 * a.cred * npad * sizeof(float);      // U[cred / 8][16][npad][8]
+    int rc = ssdseg_workspace(ctx, ubytes, &ws);
     if (rc) return rc;
     SSDSEG_LAUNCH(ctx, 4.0 * (9 + 16) * cin * cout, 0.0, conv3_wino_weights_kernel, dim3(cdiv(cout, 32), cdiv(cin, 32)), dim3(256), 0, w, (float*)ws, cin, cout, mode);
     SSDSEG_LAUNCH_CHECK();
     a.wt = (const float*)ws;
     a.tiles_h = cdiv(a.h, C3T_ROWS); a.tiles_w = cdiv(a.w, C3T_COLS); a.ntiles_n = cdiv(a.nout, WINO_NT); a.ncols = WINO_NT;
     a.in_bytes = (unsigned)((((long long)a.n * a.h * a.w - 1) * a.ldi + a.cred) * 4);
-    a.wt_bytes = (unsigned)((long long)16 * a.nout * a.cred * 4);
+    a.wt_bytes = (unsigned)ubytes;
     const size_t lds = wino_lds_floats(a.cred) * sizeof(float);
     static size_t configured = 0;
     if (lds > configured) {

@@ -1,5 +1,6 @@
 #!/bin/bash
 # MFMA / LDS counters per kernel (one PMC pass).  usage: bash scripts/gpu_mfma_counters.sh <tag> [bench args]
+#   PROG="scripts/conv3_decoder_time.py 2" bash scripts/gpu_mfma_counters.sh <tag>    profiles that script instead of bench.py
 set -o pipefail
 TAG=${1:-mfma}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -7,7 +8,7 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS \
-    --kernel-trace --output-format csv -d $OUT/pmc -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing "$@" > $OUT/pmc.log 2>&1 || { tail -5 $OUT/pmc.log; exit 1; }
+    --kernel-trace --output-format csv -d $OUT/pmc -- python3 ${PROG:+$R/}${PROG:-$R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing} "$@" > $OUT/pmc.log 2>&1 || { tail -5 $OUT/pmc.log; exit 1; }
 python3 - "$OUT" <<'PY'
 import collections, csv, glob, re, sys
 out = sys.argv[1]
