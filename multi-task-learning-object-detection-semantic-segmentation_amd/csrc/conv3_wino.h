@@ -19,8 +19,9 @@
 //                     channel pairs (j, 4+j) as in conv3_tile.h) of the positions the wave owns: the transformed input exists
 //                     neither in HBM nor in LDS, a wave multiplies what it transformed;
 //   each wave runs    4 positions x 2 column blocks x 4 MFMAs against 8 ds_read_b128 of U.
-// Software pipeline, ONE barrier per step: in iteration s the global loads of patch s+2 / weights s+1 are in flight, patch s+1
-// (staged in iteration s-1) is transformed into next step's A registers in the shadow of the MFMAs of step s.
+// Software pipeline, ONE barrier per step, placed between the MFMAs of positions 4a+1 and 4a+2 (three weight buffers make that
+// legal): in iteration s the global loads of patch s+2 / weights s+1 are in flight, patch s+1 (staged in iteration s-1) is
+// transformed into next step's A registers in the shadow of the MFMAs of step s.
 // Epilogue: each wave applies the column half of A^T . A in registers (it holds all four b of its row a), the row half sums over
 // the four a through LDS once; the threads write the 2x2 outputs and -- forward -- the BatchNorm partial sums of the block (one
 // partial row per pixel tile, fixed order, no atomics), exactly like the halo-tile kernel.
@@ -38,7 +39,7 @@ constexpr int WINO_MS_LD = 33;                       // epilogue rows of 32 chan
 constexpr int WINO_MS_F = 4 * 2 * WINO_TILES * 2 * WINO_MS_LD;     // [a][j][tile][cb][33]
 constexpr int WINO_RED_F = 2 * 2 * 8 * 32;           // [cb][sum | sumsq][tile group][32]
 constexpr size_t wino_lds_floats(int cred) {
-    const size_t loop = 2 * (size_t)(WINO_RAW_F + WINO_U_F) + 2 * (size_t)(cred + 16), epi = (size_t)WINO_MS_F + WINO_RED_F;
+    const size_t loop = 2 * (size_t)WINO_RAW_F + 3 * (size_t)WINO_U_F + 2 * (size_t)(cred + 16), epi = (size_t)WINO_MS_F + WINO_RED_F;
     return loop > epi ? loop : epi;
 }
 
@@ -49,8 +50,8 @@ __global__ void __launch_bounds__(C3T_THREADS, 2) conv3_wino_kernel(Conv3TArgs p
     constexpr int UQ = USLOTS / C3T_THREADS;
     extern __shared__ float smem[];
     // buffer offsets (floats from smem; integers, so that every access stays a DS instruction through the buffer swaps)
-    constexpr int RAW0 = 0, RAW1 = WINO_RAW_F, U0 = 2 * WINO_RAW_F, U1 = U0 + WINO_U_F;
-    float* coef = smem + U1 + WINO_U_F;                // [2][cred + 16]: scale, shift of the input view (+ spare steps)
+    constexpr int RAW0 = 0, RAW1 = WINO_RAW_F, U0 = 2 * WINO_RAW_F, U1 = U0 + WINO_U_F, U2 = U1 + WINO_U_F;
+    float* coef = smem + U2 + WINO_U_F;                // [2][cred + 16]: scale, shift of the input view (+ spare steps)
     const int cld = p.cred + 16;
 
     const int t = threadIdx.x;
@@ -177,25 +178,31 @@ __global__ void __launch_bounds__(C3T_THREADS, 2) conv3_wino_kernel(Conv3TArgs p
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[b][cb][e] = 0.f;
 
-    auto compute = [&](const float4* av, int uoff, int b) {
+    auto bfrag = [&](int uoff, int b, float4* bf) {
         const float* u = smem + uoff + (4 * ta + b) * WINO_NT * C3T_KC + foff;
-        const float4 b0 = ld4(u), b1 = ld4(u + 32 * C3T_KC);
-        const float4 a = av[b];
-        acc[b][0] = mfma32(a.x, b0.x, acc[b][0]);
-        acc[b][1] = mfma32(a.x, b1.x, acc[b][1]);
-        acc[b][0] = mfma32(a.y, b0.y, acc[b][0]);
-        acc[b][1] = mfma32(a.y, b1.y, acc[b][1]);
-        acc[b][0] = mfma32(a.z, b0.z, acc[b][0]);
-        acc[b][1] = mfma32(a.z, b1.z, acc[b][1]);
-        acc[b][0] = mfma32(a.w, b0.w, acc[b][0]);
-        acc[b][1] = mfma32(a.w, b1.w, acc[b][1]);
+        bf[0] = ld4(u);
+        bf[1] = ld4(u + 32 * C3T_KC);
+    };
+    auto mfmas = [&](const float4 a, const float4* bf, int b) {
+        acc[b][0] = mfma32(a.x, bf[0].x, acc[b][0]);
+        acc[b][1] = mfma32(a.x, bf[1].x, acc[b][1]);
+        acc[b][0] = mfma32(a.y, bf[0].y, acc[b][0]);
+        acc[b][1] = mfma32(a.y, bf[1].y, acc[b][1]);
+        acc[b][0] = mfma32(a.z, bf[0].z, acc[b][0]);
+        acc[b][1] = mfma32(a.z, bf[1].z, acc[b][1]);
+        acc[b][0] = mfma32(a.w, bf[0].w, acc[b][0]);
+        acc[b][1] = mfma32(a.w, bf[1].w, acc[b][1]);
     };
 
-    // ---- pipeline.  Invariant at the top of iteration s: acur = transformed input of step s (registers), U[s&1] = weights of step
-    // s, raw[(s+1)&1] = patch of step s+1, all visible.  Loads / commits / transforms past the last step run on harmless data
-    // (range-checked loads, spare coefficient entries) into buffers nobody reads: no conditionals around memory operations.
+    // ---- pipeline.  Top of iteration s: acur = transformed input of step s (registers), U[s % 3] = weights of step s, raw[(s+1)&1]
+    // = patch of step s+1, all visible.  The ONE barrier of a step sits in the MIDDLE of its MFMAs: positions b = 0, 1 before it,
+    // b = 2, 3 (fragments already read) after it, so the matrix pipe has queued work on both sides while the slowest wave
+    // commits.  That leaves readers of U[s % 3] (b = 2, 3 of iteration s) unordered against the commits of iteration s+1 -- which
+    // therefore go to a THIRD weight buffer, last read two barriers ago.  Loads / commits / transforms past the last step run
+    // on harmless data (range-checked loads, spare coefficient entries) into buffers nobody reads: no conditionals around
+    // memory operations in the loop.
     const int S = p.cred / C3T_KC;
-    float4 tr[4], acur[4], anxt[4];
+    float4 tr[4], acur[4], anxt[4], bf0[2], bf1[2];
     issue_raw(0);
     issue_u(0);
     __syncthreads();            // coef[] visible
@@ -207,29 +214,37 @@ __global__ void __launch_bounds__(C3T_THREADS, 2) conv3_wino_kernel(Conv3TArgs p
     transform_finish(tr, acur);
     commit_raw(1, RAW1);
     __syncthreads();
-    int rcur = RAW0, rnxt = RAW1, ucur = U0, unxt = U1;
+    int rcur = RAW0, rnxt = RAW1, ucur = U0, unxt = U1, ufar = U2;
     for (int s = 0; s < S; ++s) {
         issue_raw(s + 2);
         issue_u(s + 1);
+        bfrag(ucur, 0, bf0);
         transform_load(rnxt, tr);       // step s+1: the patch reads go out ahead of the first MFMA block ...
         __builtin_amdgcn_sched_barrier(0);
-        compute(acur, ucur, 0);         // step s
+        mfmas(acur[0], bf0, 0);
         __builtin_amdgcn_sched_barrier(0);
         transform_finish(tr, anxt);     // ... the additions run in its shadow
+        bfrag(ucur, 1, bf1);
         __builtin_amdgcn_sched_barrier(0);
-        compute(acur, ucur, 1);
-        compute(acur, ucur, 2);
-        compute(acur, ucur, 3);
+        mfmas(acur[1], bf1, 1);
         __builtin_amdgcn_sched_barrier(0);
+        bfrag(ucur, 2, bf0);
         commit_raw(s + 2, rcur);        // last read by the transform of iteration s-1, one barrier ago
-        commit_u(unxt);                 // last read by compute(s-1)
+        commit_u(unxt);                 // U[(s+1) % 3]: last read by b = 2, 3 of iteration s-2, two barriers ago
         __syncthreads();
+        mfmas(acur[2], bf0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        bfrag(ucur, 3, bf1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(acur[3], bf1, 3);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int b = 0; b < 4; ++b) acur[b] = anxt[b];
         int x;
         x = rcur; rcur = rnxt; rnxt = x;
-        x = ucur; ucur = unxt; unxt = x;
+        x = ucur; ucur = unxt; unxt = ufar; ufar = x;
     }
+    __syncthreads();            // every wave is done with the operand buffers: the epilogue reuses them
 
     // ---- epilogue.  C/D layout of a 32x32 accumulator: column = lane & 31 (output channel), row = (e & 3) + 8 * (e >> 2) + 4 * hh (tile).
     //   A^T = [1 1 1 0; 0 1 -1 -1]:  y[i][j] = sum_ab A^T[i][a] m[a][b] A^T[j][b].  The wave holds all four b of its row a: the
