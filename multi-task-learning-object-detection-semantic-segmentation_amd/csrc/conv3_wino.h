@@ -19,7 +19,7 @@
 //                     channel pairs (j, 4+j) as in conv3_tile.h) of the positions the wave owns: the transformed input exists
 //                     neither in HBM nor in LDS, a wave multiplies what it transformed;
 //   each wave runs    4 positions x 2 column blocks x 4 MFMAs against 8 ds_read_b128 of U.
-// Software pipeline, ONE barrier per step, placed between the MFMAs of positions 4a+1 and 4a+2 (three weight buffers make that
+// Software pipeline, ONE barrier per step, placed between the MFMAs of positions 4a+2 and 4a+3 (three weight buffers make that
 // legal): in iteration s the global loads of patch s+2 / weights s+1 are in flight, patch s+1 (staged in iteration s-1) is
 // transformed into next step's A registers in the shadow of the MFMAs of step s.
 // Epilogue: each wave applies the column half of A^T . A in registers (it holds all four b of its row a), the row half sums over
@@ -43,11 +43,16 @@ constexpr size_t wino_lds_floats(int cred) {
     return loop > epi ? loop : epi;
 }
 
+template <int V> struct wino_const { static constexpr int value = V; };
+
+// VIEW: the input carries a BatchNorm / activation view (else the staged values are stored as loaded: an identity view costs no
+// VALU work -- every vector instruction in the loop takes issue slots from the MFMAs, measured ~4 cycles each)
+template <bool VIEW>
 __global__ void __launch_bounds__(C3T_THREADS, 2) conv3_wino_kernel(Conv3TArgs p) {
     constexpr int PSLOTS = C3T_PIX * 2;                // float4 slots of a patch (680)
     constexpr int PQ = (PSLOTS + C3T_THREADS - 1) / C3T_THREADS;
     constexpr int USLOTS = 16 * WINO_NT * 2;           // float4 slots of a weight slice (2048)
-    constexpr int UQ = USLOTS / C3T_THREADS;
+    constexpr int UQ = USLOTS / C3T_THREADS;          // 4 per thread
     extern __shared__ float smem[];
     // buffer offsets (floats from smem; integers, so that every access stays a DS instruction through the buffer swaps)
     constexpr int RAW0 = 0, RAW1 = WINO_RAW_F, U0 = 2 * WINO_RAW_F, U1 = U0 + WINO_U_F, U2 = U1 + WINO_U_F;
@@ -82,11 +87,10 @@ __global__ void __launch_bounds__(C3T_THREADS, 2) conv3_wino_kernel(Conv3TArgs p
 
     // ---- staging slots (fixed per thread): raw buffer loads, 32-bit offsets, hardware range check (offset 2^31 -> zeros)
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rwt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, p.wt_bytes, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     const int npad = p.ntiles_n * WINO_NT;
-    unsigned pgo[PQ], ugo[UQ];
-    int plo[PQ], ulo[UQ];
+    unsigned pgo[PQ];
+    int plo[PQ];
     unsigned inimg = 0;      // bit q: patch slot q is an image pixel (else zero padding -- NOT act(shift))
 #pragma unroll
     for (int q = 0; q < PQ; ++q) {
@@ -99,44 +103,47 @@ __global__ void __launch_bounds__(C3T_THREADS, 2) conv3_wino_kernel(Conv3TArgs p
         plo[q] = slot < PSLOTS ? raw_off(prow, pcol, chunk) : -1;
         inimg |= (ok ? 1u : 0u) << q;
     }
-#pragma unroll
-    for (int q = 0; q < UQ; ++q) {
-        const int slot = t + C3T_THREADS * q;
-        const int chunk = slot & 1, rowi = slot >> 1;          // rowi = k * 64 + nn
-        const int nn = rowi & (WINO_NT - 1), k = rowi / WINO_NT;
-        const bool ok = n0 + nn < p.nout;
-        ugo[q] = ok ? (unsigned)((((long long)k * npad + n0 + nn) * C3T_KC + 4 * chunk) * 4) : OOB;      // + step * ustep bytes
-        ulo[q] = rowi * C3T_KC + 4 * (chunk ^ ((nn >> 3) & 1));
-    }
+    // weights by LDS-DMA (buffer_load ... lds: no registers, no ds_write): the LDS image is lane-linear -- slot = t + 512 q lands
+    // at 16 * slot bytes, row = slot >> 1 = k * 64 + nn, LDS half = slot & 1 -- so the swizzle goes on the SOURCE half.  A
+    // thread's four slots sit 256 rows = 4 positions apart: one offset register.
+    const int urow = t >> 1, unn = urow & (WINO_NT - 1);
+    const unsigned ugo0 = (n0 + unn < p.nout) ? (unsigned)((((long long)(urow >> 6) * npad + n0 + unn) * C3T_KC + 4 * ((t & 1) ^ ((unn >> 3) & 1))) * 4) : OOB;
+    const unsigned uqstep = (unsigned)(4 * npad * C3T_KC * 4);       // bytes between a thread's slots (4 positions)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int pchunk = t & 1;
     const int ustep = 16 * npad * C3T_KC * 4;          // bytes of one step of U[step][k][npad][8]
 
-    float4 preg[PQ], ureg[UQ];
+    float4 preg[PQ];
     auto issue_raw = [&](int s) {
         const int soff = s * C3T_KC * 4;
 #pragma unroll
         for (int q = 0; q < PQ; ++q) preg[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rin, pgo[q], soff, 0));
     };
-    auto issue_u = [&](int s) {
+    const pwt_i32x4 rwt = pwt_make_rsrc(p.wt, p.wt_bytes);
+    auto issue_u = [&](int s, int boff) {      // weights of step s -> LDS buffer at float offset boff, asynchronously
         const int soff = s * ustep;
 #pragma unroll
-        for (int q = 0; q < UQ; ++q) ureg[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rwt, ugo[q], soff, 0));
+        for (int q = 0; q < UQ; ++q) {
+            const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((boff + (wave_u * 64 + C3T_THREADS * q) * 4) * 4);
+            lds_dma16(rwt, dst, ugo0 + q * uqstep, soff);
+        }
     };
     auto commit_raw = [&](int s, int boff) {
         float* buf = smem + boff;
-        const int c0 = s * C3T_KC + 4 * pchunk;
-        const float4 cs = ld4(coef + c0), ct = ld4(coef + cld + c0);
+        if (VIEW) {
+            const int c0 = s * C3T_KC + 4 * pchunk;
+            const float4 cs = ld4(coef + c0), ct = ld4(coef + cld + c0);
 #pragma unroll
-        for (int q = 0; q < PQ; ++q) {
-            if (plo[q] >= 0) st4(buf + plo[q], ((inimg >> q) & 1u) ? view_affine4(preg[q], cs, ct, alo, ahi) : f4(0.f));
+            for (int q = 0; q < PQ; ++q) {
+                if (plo[q] >= 0) st4(buf + plo[q], ((inimg >> q) & 1u) ? view_affine4(preg[q], cs, ct, alo, ahi) : f4(0.f));
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < PQ; ++q) {
+                if (plo[q] >= 0) st4(buf + plo[q], preg[q]);       // padding slots loaded zeros (range-checked offset)
+            }
         }
     };
-    auto commit_u = [&](int boff) {
-        float* buf = smem + boff;
-#pragma unroll
-        for (int q = 0; q < UQ; ++q) st4(buf + ulo[q], ureg[q]);
-    };
-
     // ---- roles.  Wave = (row a of the 4x4 transformed tile: wave >> 1, half of the block's tiles: wave & 1); lane = (tile of that
     // half: lane & 31, 4-channel quad: lane >> 5).  The lane forms V[a][0..3] = (B^T d B)[a][.] of ITS tile and quad in registers
     //   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]:  row a combines patch rows (i0, i1) = (0,2) (1,2) (2,1) (1,3), sign - + - -
@@ -169,7 +176,7 @@ __global__ void __launch_bounds__(C3T_THREADS, 2) conv3_wino_kernel(Conv3TArgs p
     };
 
     // ---- MFMAs: positions k = 4a + b, rows = the wave's 32 tiles, columns = output channels cb * 32 + li
-    const int foff = li * C3T_KC + 4 * (hh ^ ((li >> 3) & 1));
+    const int fbase = 4 * ta * WINO_NT * C3T_KC + li * C3T_KC + 4 * (hh ^ ((li >> 3) & 1));
     f32x16 acc[4][2];
 #pragma unroll
     for (int b = 0; b < 4; ++b)
@@ -179,9 +186,9 @@ __global__ void __launch_bounds__(C3T_THREADS, 2) conv3_wino_kernel(Conv3TArgs p
             for (int e = 0; e < 16; ++e) acc[b][cb][e] = 0.f;
 
     auto bfrag = [&](int uoff, int b, float4* bf) {
-        const float* u = smem + uoff + (4 * ta + b) * WINO_NT * C3T_KC + foff;
-        bf[0] = ld4(u);
-        bf[1] = ld4(u + 32 * C3T_KC);
+        const float* u = smem + uoff + fbase;
+        bf[0] = ld4(u + b * WINO_NT * C3T_KC);
+        bf[1] = ld4(u + b * WINO_NT * C3T_KC + 32 * C3T_KC);
     };
     auto mfmas = [&](const float4 a, const float4* bf, int b) {
         acc[b][0] = mfma32(a.x, bf[0].x, acc[b][0]);
@@ -195,55 +202,64 @@ __global__ void __launch_bounds__(C3T_THREADS, 2) conv3_wino_kernel(Conv3TArgs p
     };
 
     // ---- pipeline.  Top of iteration s: acur = transformed input of step s (registers), U[s % 3] = weights of step s, raw[(s+1)&1]
-    // = patch of step s+1, all visible.  The ONE barrier of a step sits in the MIDDLE of its MFMAs: positions b = 0, 1 before it,
-    // b = 2, 3 (fragments already read) after it, so the matrix pipe has queued work on both sides while the slowest wave
-    // commits.  That leaves readers of U[s % 3] (b = 2, 3 of iteration s) unordered against the commits of iteration s+1 -- which
-    // therefore go to a THIRD weight buffer, last read two barriers ago.  Loads / commits / transforms past the last step run
+    // = patch of step s+1, all visible.  The ONE barrier of a step sits INSIDE its MFMAs: positions b = 0..2 before it (the global
+    // loads issued at the top have three MFMA blocks to land), b = 3 (fragments already read) after it, so the matrix pipe has
+    // queued work on both sides while the slowest wave commits.  That leaves readers of U[s % 3] (b = 3 of iteration s)
+    // unordered against the commits of iteration s+1 -- which therefore go to a THIRD weight buffer, last read two barriers ago.  Loads / commits / transforms past the last step run
     // on harmless data (range-checked loads, spare coefficient entries) into buffers nobody reads: no conditionals around
     // memory operations in the loop.
     const int S = p.cred / C3T_KC;
-    float4 tr[4], acur[4], anxt[4], bf0[2], bf1[2];
+    float4 tr[4], av[2][4], bf0[2], bf1[2];
     issue_raw(0);
-    issue_u(0);
+    issue_u(0, U0);
     __syncthreads();            // coef[] visible
     commit_raw(0, RAW0);
-    commit_u(U0);
     issue_raw(1);
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // the DMA of step 0 has landed (the two patch loads of step 1 may still fly)
     __syncthreads();
     transform_load(RAW0, tr);
-    transform_finish(tr, acur);
+    transform_finish(tr, av[0]);
     commit_raw(1, RAW1);
     __syncthreads();
-    int rcur = RAW0, rnxt = RAW1, ucur = U0, unxt = U1, ufar = U2;
-    for (int s = 0; s < S; ++s) {
+    int ucur = U0, unxt = U1, ufar = U2;
+    bfrag(ucur, 0, bf0);
+    // one step; PH = s & 1 selects the patch buffers and the A register sets at compile time (the loop is unrolled by two)
+    auto step = [&](auto PH, int s) {
+        constexpr int ph = decltype(PH)::value;
+        constexpr int rcur = ph ? RAW1 : RAW0, rnxt = ph ? RAW0 : RAW1;
+        // every block of 8 MFMAs runs on fragments read one block earlier; bf0 of position 0 was read at the end of the last step
+        issue_u(s + 1, unxt);           // U[(s+1) % 3]: last read by the last MFMA block of step s-2, two barriers ago
         issue_raw(s + 2);
-        issue_u(s + 1);
-        bfrag(ucur, 0, bf0);
         transform_load(rnxt, tr);       // step s+1: the patch reads go out ahead of the first MFMA block ...
-        __builtin_amdgcn_sched_barrier(0);
-        mfmas(acur[0], bf0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        transform_finish(tr, anxt);     // ... the additions run in its shadow
         bfrag(ucur, 1, bf1);
         __builtin_amdgcn_sched_barrier(0);
-        mfmas(acur[1], bf1, 1);
+        mfmas(av[ph][0], bf0, 0);
         __builtin_amdgcn_sched_barrier(0);
+        transform_finish(tr, av[ph ^ 1]);     // ... the additions run in its shadow
         bfrag(ucur, 2, bf0);
-        commit_raw(s + 2, rcur);        // last read by the transform of iteration s-1, one barrier ago
-        commit_u(unxt);                 // U[(s+1) % 3]: last read by b = 2, 3 of iteration s-2, two barriers ago
-        __syncthreads();
-        mfmas(acur[2], bf0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(av[ph][1], bf1, 1);
         __builtin_amdgcn_sched_barrier(0);
         bfrag(ucur, 3, bf1);
         __builtin_amdgcn_sched_barrier(0);
-        mfmas(acur[3], bf1, 3);
+        mfmas(av[ph][2], bf0, 2);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acur[b] = anxt[b];
-        int x;
-        x = rcur; rcur = rnxt; rnxt = x;
-        x = ucur; ucur = unxt; unxt = ufar; ufar = x;
+        commit_raw(s + 2, rcur);        // last read by the transform of step s-1, one barrier ago (its wait covers the DMA issued first)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        bfrag(unxt, 0, bf0);            // position 0 of step s+1 (committed before the barrier)
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(av[ph][3], bf1, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        const int x = ucur;
+        ucur = unxt; unxt = ufar; ufar = x;
+    };
+    int s = 0;
+    for (; s + 2 <= S; s += 2) {
+        step(wino_const<0>{}, s);
+        step(wino_const<1>{}, s + 1);
     }
+    if (s < S) step(wino_const<0>{}, s);
     __syncthreads();            // every wave is done with the operand buffers: the epilogue reuses them
 
     // ---- epilogue.  C/D layout of a 32x32 accumulator: column = lane & 31 (output channel), row = (e & 3) + 8 * (e >> 2) + 4 * hh (tile).

@@ -837,8 +837,8 @@ int rowA_wn(int rows, int cols) { return pick_wn(cols, cdiv(rows, BM)); }
 #include "conv3_wgrad.h"
 #include "conv3_tile.h"
 #include "conv3_wgrad_tile.h"
-#include "conv3_wino.h"
 #include "pw_tile.h"
+#include "conv3_wino.h"
 
 // ---- tile GEMM of the pointwise convs (pw_tile.h): shape -> (waves, column tile), launch
 // SSDSEG_PW_TILE: "0" never, "1" every shape the kernel takes, unset: where it measured faster
@@ -1408,7 +1408,8 @@ int conv3_wino_launch(ssdseg_ctx* ctx, Conv3TArgs a, const float* w, int cin, in
     const size_t lds = wino_lds_floats(a.cred) * sizeof(float);
     static size_t configured = 0;
     if (lds > configured) {
-        SSDSEG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SSDSEG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wino_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SSDSEG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wino_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = lds;
     }
     const double m = (double)a.n * a.h * a.w;
@@ -1416,7 +1417,10 @@ int conv3_wino_launch(ssdseg_ctx* ctx, Conv3TArgs a, const float* w, int cin, in
     const double cost_flops = 18.0 * m * a.cred * a.nout;                                // of the convolution (the kernel executes 16/36 of them)
     const int mtiles = a.n * a.tiles_h * a.tiles_w;
     const char* kname = ctx->timing ? ssdseg_intern(mode ? "conv3_wino_kernel [bwd_data]" : "conv3_wino_kernel [fwd]") : "";
-    SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, conv3_wino_kernel, dim3((unsigned)(mtiles * a.ntiles_n)), dim3(C3T_THREADS), lds, a);
+    if (a.cs != nullptr || a.act != SSDSEG_ACT_NONE)
+        SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, conv3_wino_kernel<true>, dim3((unsigned)(mtiles * a.ntiles_n)), dim3(C3T_THREADS), lds, a);
+    else
+        SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, conv3_wino_kernel<false>, dim3((unsigned)(mtiles * a.ntiles_n)), dim3(C3T_THREADS), lds, a);
     SSDSEG_LAUNCH_CHECK();
     return 0;
 }

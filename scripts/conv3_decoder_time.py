@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Decoder 3x3 conv (304 -> 256 at 120x160, batch 32: the layer that is 45% of the full step) forward / input gradient / weight
-gradient in isolation, under the kernel switches of the environment.  usage: python scripts/conv3_decoder_time.py [reps] [batch]
+gradient in isolation, under the kernel switches of the environment.  usage: python scripts/conv3_decoder_time.py [reps] [batch] [cin] [cout]
 prints per kernel: launches, ms per launch, TFLOP/s by the convolution's flops; and a parity check against the direct kernels."""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,7 +10,9 @@ from ssdseglib import _hip as H
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-h, w, cin, cout, ldx = 120, 160, 304, 256, 304
+cin = int(sys.argv[3]) if len(sys.argv) > 3 else 304
+cout = int(sys.argv[4]) if len(sys.argv) > 4 else 256
+h, w, ldx = 120, 160, cin
 ctx = H.Context(0)
 rng = np.random.default_rng(7)
 x = ctx.array(np.clip(rng.normal(0.5, 1.5, (n, h, w, cin)), 0, 6).astype(np.float32))
