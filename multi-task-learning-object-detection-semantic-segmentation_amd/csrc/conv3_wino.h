@@ -100,7 +100,9 @@ __global__ void __launch_bounds__(C3T_THREADS, 2) conv3_wino_kernel(Conv3TArgs p
         const int gh = h0 - 1 + prow, gw = w0 - 1 + pcol;
         const bool ok = slot < PSLOTS && gh >= 0 && gh < p.h && gw >= 0 && gw < p.w;
         pgo[q] = ok ? (unsigned)(((((long long)img * p.h + gh) * p.w + gw) * p.ldi + 4 * chunk) * 4) : OOB;
-        plo[q] = slot < PSLOTS ? raw_off(prow, pcol, chunk) : -1;
+        // a thread without a second slot writes to the four spare pixels at the end of the plane: the stores stay unconditional
+        // (a branch around them would also skip the load's s_waitcnt, and the compiler would re-insert it -- counting the DMAs -- later)
+        plo[q] = slot < PSLOTS ? raw_off(prow, pcol, chunk) : (chunk * WINO_PIXP + C3T_PIX + (t & 3)) * 4;
         inimg |= (ok ? 1u : 0u) << q;
     }
     // weights by LDS-DMA (buffer_load ... lds: no registers, no ds_write): the LDS image is lane-linear -- slot = t + 512 q lands
@@ -135,13 +137,13 @@ __global__ void __launch_bounds__(C3T_THREADS, 2) conv3_wino_kernel(Conv3TArgs p
             const float4 cs = ld4(coef + c0), ct = ld4(coef + cld + c0);
 #pragma unroll
             for (int q = 0; q < PQ; ++q) {
-                if (plo[q] >= 0) st4(buf + plo[q], ((inimg >> q) & 1u) ? view_affine4(preg[q], cs, ct, alo, ahi) : f4(0.f));
+                const float keep = ((inimg >> q) & 1u) ? 1.f : 0.f;      // zero padding AFTER the view, branch-free
+                const float4 v = view_affine4(preg[q], cs, ct, alo, ahi);
+                st4(buf + plo[q], make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep));
             }
         } else {
 #pragma unroll
-            for (int q = 0; q < PQ; ++q) {
-                if (plo[q] >= 0) st4(buf + plo[q], preg[q]);       // padding slots loaded zeros (range-checked offset)
-            }
+            for (int q = 0; q < PQ; ++q) st4(buf + plo[q], preg[q]);       // padding slots loaded zeros (range-checked offset)
         }
     };
     // ---- roles.  Wave = (row a of the 4x4 transformed tile: wave >> 1, half of the block's tiles: wave & 1); lane = (tile of that
@@ -173,6 +175,9 @@ __global__ void __launch_bounds__(C3T_THREADS, 2) conv3_wino_kernel(Conv3TArgs p
         v[1] = make_float4(r[1].x + r[2].x, r[1].y + r[2].y, r[1].z + r[2].z, r[1].w + r[2].w);
         v[2] = make_float4(r[2].x - r[1].x, r[2].y - r[1].y, r[2].z - r[1].z, r[2].w - r[1].w);
         v[3] = make_float4(r[1].x - r[3].x, r[1].y - r[3].y, r[1].z - r[3].z, r[1].w - r[3].w);
+        // the values are not used before the next step: keep the compiler from sinking the arithmetic down to the barrier
+#pragma unroll
+        for (int b = 0; b < 4; ++b) asm volatile("" : "+v"(v[b].x), "+v"(v[b].y), "+v"(v[b].z), "+v"(v[b].w));
     };
 
     // ---- MFMAs: positions k = 4a + b, rows = the wave's 32 tiles, columns = output channels cb * 32 + li
@@ -230,12 +235,12 @@ __global__ void __launch_bounds__(C3T_THREADS, 2) conv3_wino_kernel(Conv3TArgs p
         // every block of 8 MFMAs runs on fragments read one block earlier; bf0 of position 0 was read at the end of the last step
         issue_u(s + 1, unxt);           // U[(s+1) % 3]: last read by the last MFMA block of step s-2, two barriers ago
         issue_raw(s + 2);
-        transform_load(rnxt, tr);       // step s+1: the patch reads go out ahead of the first MFMA block ...
         bfrag(ucur, 1, bf1);
         __builtin_amdgcn_sched_barrier(0);
         mfmas(av[ph][0], bf0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        transform_finish(tr, av[ph ^ 1]);     // ... the additions run in its shadow
+        transform_load(rnxt, tr);       // step s+1, between two MFMA blocks: the other wave of the SIMD has the matrix pipe meanwhile
+        transform_finish(tr, av[ph ^ 1]);
         bfrag(ucur, 2, bf0);
         __builtin_amdgcn_sched_barrier(0);
         mfmas(av[ph][1], bf1, 1);
