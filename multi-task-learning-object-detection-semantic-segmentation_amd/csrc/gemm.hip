@@ -839,6 +839,7 @@ int rowA_wn(int rows, int cols) { return pick_wn(cols, cdiv(rows, BM)); }
 #include "conv3_wgrad_tile.h"
 #include "pw_tile.h"
 #include "conv3_wino.h"
+#include "conv3_wino_wgrad.h"
 
 // ---- tile GEMM of the pointwise convs (pw_tile.h): shape -> (waves, column tile), launch
 // SSDSEG_PW_TILE: "0" never, "1" every shape the kernel takes, unset: where it measured faster
@@ -1425,6 +1426,58 @@ int conv3_wino_launch(ssdseg_ctx* ctx, Conv3TArgs a, const float* w, int cin, in
     return 0;
 }
 
+// weight gradient in the Winograd form (conv3_wino_wgrad.h): h even, w a multiple of 32, everything below 2^31 bytes
+bool conv3_wino_wgrad_takes(int n, int h, int w, int cin, int cout) {
+    const int mode = conv3_wino_mode();
+    if (mode == 0 || h % 2 != 0 || w % 32 != 0) return false;
+    if ((long long)n * (h + 2) * (w + 2) * cin * 4 >= (1LL << 31) || (long long)n * h * w * cout * 4 >= (1LL << 31)) return false;
+    return mode == 1 || (long long)n * (h / 2) * (w / 32) >= 512;
+}
+
+int conv3_wino_wgrad_launch(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const float* dy, float* dw, int n, int h, int w, int cin, int cout) {
+    WinoWgArgs a{};
+    a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout;
+    a.cpatches = cdiv(cin, WWG_KT); a.npatches = cdiv(cout, WWG_NT);
+    a.strips = w / 32;
+    a.steps = n * (h / 2) * a.strips;
+    const int patches = a.cpatches * a.npatches;
+    int splits = ctx->num_cus / patches;                    // one block per CU (100 KB of LDS, 8 waves)
+    if (splits > a.steps / 4) splits = a.steps / 4;
+    if (splits < 1) splits = 1;
+    a.steps_per_split = (a.steps + splits - 1) / splits;
+    splits = (a.steps + a.steps_per_split - 1) / a.steps_per_split;
+    const size_t xpb = align256((size_t)n * (h + 2) * (w + 2) * cin * sizeof(float));
+    const size_t pb = (size_t)splits * 16 * cin * cout * sizeof(float);
+    SSDSEG_ARG(pb < ((size_t)1 << 31), 9);
+    void* ws;
+    int rc = ssdseg_workspace(ctx, xpb + pb, &ws);
+    if (rc) return rc;
+    float* xp = (float*)ws;
+    a.xp = xp; a.dy = dy; a.part = (float*)((char*)ws + xpb);
+    a.xp_bytes = (unsigned)((size_t)n * (h + 2) * (w + 2) * cin * sizeof(float));
+    a.dy_bytes = (unsigned)((size_t)n * h * w * cout * sizeof(float));
+    a.part_bytes = (unsigned)pb;
+    const double m = (double)n * h * w;
+    const long long tot4 = (long long)n * (h + 2) * (w + 2) * (cin / 4);
+    SSDSEG_LAUNCH(ctx, 8.0 * m * cin, 0.0, conv3_pad_view_kernel, dim3((unsigned)((tot4 + 255) / 256 < 16384 ? (tot4 + 255) / 256 : 16384)), dim3(256), 0, in->x,
+                  in->scale, in->shift, in->act, ldx, xp, n, h, w, cin);
+    SSDSEG_LAUNCH_CHECK();
+    static bool configured = false;   // dynamic LDS beyond 64 KiB has to be announced once
+    if (!configured) {
+        SSDSEG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wino_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WWG_LDS_BYTES));
+        configured = true;
+    }
+    const double cost_bytes = 4.0 * (m * cin + m * cout + 9.0 * cin * cout);   // X + dY + dW
+    const double cost_flops = 18.0 * m * cin * cout;                            // of the convolution (the kernel executes 16/36 of them)
+    SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, conv3_wino_wgrad_kernel, dim3((unsigned)(patches * splits)), dim3(WWG_THREADS), WWG_LDS_BYTES, a);
+    SSDSEG_LAUNCH_CHECK();
+    const long long cn = (long long)cin * cout;
+    SSDSEG_LAUNCH(ctx, 4.0 * cn * (16.0 * splits + 9.0), 0.0, conv3_wino_wgrad_finalize_kernel, dim3((unsigned)((cn + 255) / 256)), dim3(256), 0, (const float*)a.part, dw,
+                  splits, cin, cout);
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1975,6 +2028,8 @@ int ssdseg_conv3x3_bwd_weight(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, c
         return 0;
     }
     const char* c3env = getenv("SSDSEG_CONV3_WGRAD");   // "taps": the nine shifted GEMMs (A/B measurements, parity tests)
+    if (c3env == nullptr && dy->scale == nullptr && conv3_wino_wgrad_takes(n, h, wdt, cin, cout))
+        return conv3_wino_wgrad_launch(ctx, in, ldx, dy->g, dw, n, h, wdt, cin, cout);
     if (c3env == nullptr && conv3_tile_enabled() && dy->scale == nullptr && conv3_tile_fits(n, h, wdt, ldx) && conv3_tile_fits(n, h, wdt, cout)) {
         // halo-tile form (conv3_wgrad_tile.h): 64 x 64 (k, n) tiles of all nine taps, one image row x 32 columns per step
         Wg3TArgs a{};

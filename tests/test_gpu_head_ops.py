@@ -41,7 +41,9 @@ def gview_inputs(rng, shape, act):
 @pytest.mark.parametrize("n,h,w,cin,cout", [(2, 9, 11, 16, 32), (1, 12, 16, 304, 256), (2, 8, 8, 256, 4), (1, 5, 5, 24, 8), (1, 1, 1, 8, 8),
                                             (3, 14, 40, 72, 96),    # 40 = one full + one partial 32-pixel step / tile per image row
                                             (2, 17, 33, 40, 200),   # odd number of 8-channel steps; two 100-column tiles of a 128-wide block
-                                            (1, 8, 32, 12, 16)])    # cin not a multiple of 8: the implicit-GEMM forward, halo-tile backward
+                                            (1, 8, 32, 12, 16),     # cin not a multiple of 8: the implicit-GEMM forward, halo-tile backward
+                                            (2, 6, 64, 80, 72),     # even h, w a multiple of 32: the Winograd weight gradient ("wino"), partial 64-channel patches, 3 splits
+                                            (3, 2, 32, 64, 64)])    # one tile row per image: every step crosses an image border of the padded copy
 # kernel family: "narrow" = cout <= 8 as tap-expanded pointwise GEMMs (default for those shapes); "tile" = the halo-tile kernels
 # (conv3_tile.h); "wino" = the Winograd F(2x2, 3x3) kernels forced at every size (conv3_wino.h, default for the large layers: same
 # tolerance -- its transforms are additions and halvings); "gemm" = the implicit-GEMM kernels
