@@ -431,6 +431,13 @@ def main():
                 "hbm_GBps_incl_view_bytes": round((alg_bytes + view_bytes) / (avg_ms * 1e-3) / 1e9, 1),
                 "traffic_over_algorithmic": round(traffic / alg_bytes, 3) if traffic else None,
             }
+            if name.startswith("conv3_wino"):
+                # Winograd F(2x2, 3x3), fp32: the kernel executes 16 multiply-adds per 2x2 output tile and channel pair where the
+                # direct form has 36.  `achieved` / `frac` above count the flops EXECUTED on the MFMA pipe (a utilisation, <= 1);
+                # the figure by the direct convolution's 18 m cin cout flops -- SURVEY.md 8(d)'s unit -- is reported here.
+                out["roofline"]["algorithm"] = "winograd F(2x2,3x3), fp32 transforms and accumulation"
+                out["roofline"]["direct_equivalent"] = {"flops_per_launch": dom["flops"] / dom["count"] * 2.25, "TFLOP/s": round(tfs * 2.25, 2),
+                                                        "over_peak": round(mfma_frac * 2.25, 4)}
             ach = achievable_ceiling(bound)
             if ach is not None:
                 # extra context, not the contract's `peak`: what a trivial micro-benchmark sustains on this chip (committed summary)

@@ -538,9 +538,11 @@ int ssdseg_dwconv_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, fl
     if (dw_fwd_use_march(n, h, wdt, c, dilation)) {
         March2Geom mg;
         const MarchLaunch ml = march_fwd_geometry(n, h, wdt, c, g.ho, g.wo, stride, &mg, dilation);
+        { const char* e = getenv("SSDSEG_DW_FWD_DEPTH"); mg.depth2 = !(e != nullptr && e[0] == '1'); }
 #define DW_FWD_MARCH(S_, PT_, PL_, DIL_) \
     SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_fwd_march_kernel<S_, PT_, PL_, DIL_>), ml.grid, ml.block, ml.lds, mg, v, w, y, stats)
         if (dilation > 1) DW_FWD_MARCH(1, 1, 1, true);
+        else if (stride == 1 && mg.depth2) SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, (dw_fwd_march_kernel<1, 1, 1, false, true>), ml.grid, ml.block, ml.lds, mg, v, w, y, stats);
         else if (stride == 1) DW_FWD_MARCH(1, 1, 1, false);
         else if (g.pt == 0 && g.pl == 0) DW_FWD_MARCH(2, 0, 0, false);
         else if (g.pt == 0) DW_FWD_MARCH(2, 0, 1, false);

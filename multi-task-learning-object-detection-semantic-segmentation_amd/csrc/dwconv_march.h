@@ -293,6 +293,7 @@ struct March2Geom {
     int n, h, w, c, ho, wo;
     int rows, chunks, wstrips, cb, spb, sblocks, sgroups;   // as MarchGeom, over the OUTPUT rows / 2-column output strips
     int dil;                                                // forward DIL kernels: see MarchGeom::dil
+    int depth2;                                             // forward: loads two rows ahead (three stage sets) instead of one
 };
 
 // ACC: dx += result.  The old values are fetched WITH the step's other loads (one step ahead); read inline at the store they
@@ -490,7 +491,7 @@ __global__ void __launch_bounds__(MARCH_MAX_THREADS) __attribute__((amdgpu_waves
 // BN statistics (sum, sumsq of the raw output) stay in registers and leave as one partial row per block.
 // `gm` is a March2Geom in both cases (h, w input; ho, wo output; strips over output columns).
 // DIL (S == 1, PT == PL == 1): atrous conv as dil^2 interleaved dense convs over the sub-grids, as in the backward kernel
-template <int S, int PT, int PL, bool DIL = false>
+template <int S, int PT, int PL, bool DIL = false, bool D2 = false>
 __global__ void __launch_bounds__(MARCH_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) dw_fwd_march_kernel(March2Geom gm, ViewDev in, const float* __restrict__ wgt, float* __restrict__ y,
                                                             float* __restrict__ stats) {
     constexpr int OC = S == 1 ? 4 : 2;        // output columns per thread
@@ -604,14 +605,61 @@ __global__ void __launch_bounds__(MARCH_MAX_THREADS) __attribute__((amdgpu_waves
                 for (int b = 0; b < IC; ++b) wa[0][b] = wa[2][b];
             }
         };
-        Stage sa, sb2;
-        issue(r0, sa);
-        int r = r0;
-        for (; r + 1 < r1; r += 2) {
-            step(r, sa, sb2);
-            step(r + 1, sb2, sa);
+        // loads run TWO rows ahead of the arithmetic (three stage sets in rotation): with one row ahead a wave had 1.5 KB in flight,
+        // 24-48 KB per CU -- at the edge of what 5 TB/s x ~2 us of loaded HBM latency asks for (SSDSEG_DW_FWD_DEPTH=1: the old depth)
+        if (D2) {
+            auto step2 = [&](int r, Stage& cur, Stage& far) {      // `far` receives row r + 2
+                if (S == 1) {
+                    activate(r + 2 - PT, cur.x[0], wa[2]);
+                } else {
+                    activate(2 * r - PT + 1, cur.x[0], wa[1]);
+                    activate(2 * r - PT + 2, cur.x[NR - 1], wa[2]);
+                }
+                issue(r + 3, far);
+                const unsigned ob = obase + (unsigned)r * orow + (unsigned)wo0 * ocol;
+#pragma unroll
+                for (int j = 0; j < OC; ++j) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) acc = fmaf(wa[kh][j * S + kw], wk[kh * 3 + kw], acc);
+                    if (wo0 + j < wwo) {
+                        *reinterpret_cast<float*>(reinterpret_cast<char*>(y) + (ob + (unsigned)j * ocol)) = acc;
+                        ssum += acc;
+                        ssq = fmaf(acc, acc, ssq);
+                    }
+                }
+                if (S == 1) {
+#pragma unroll
+                    for (int b = 0; b < IC; ++b) { wa[0][b] = wa[1][b]; wa[1][b] = wa[2][b]; }
+                } else {
+#pragma unroll
+                    for (int b = 0; b < IC; ++b) wa[0][b] = wa[2][b];
+                }
+            };
+            Stage s0, s1, s2;
+            issue(r0, s0);
+            issue(r0 + 1, s1);
+            issue(r0 + 2, s2);
+            int r = r0;
+            for (; r + 2 < r1; r += 3) {
+                step2(r, s0, s0);          // consumes s0 (row r), refills it with row r + 3
+                step2(r + 1, s1, s1);
+                step2(r + 2, s2, s2);
+            }
+            if (r < r1) step2(r, s0, s0);
+            if (r + 1 < r1) step2(r + 1, s1, s1);
+        } else {
+            Stage sa, sb2;
+            issue(r0, sa);
+            int r = r0;
+            for (; r + 1 < r1; r += 2) {
+                step(r, sa, sb2);
+                step(r + 1, sb2, sa);
+            }
+            if (r < r1) step(r, sa, sb2);
         }
-        if (r < r1) step(r, sa, sb2);
     }
 
     if (stats != nullptr) {

@@ -1415,7 +1415,9 @@ int conv3_wino_launch(ssdseg_ctx* ctx, Conv3TArgs a, const float* w, int cin, in
     }
     const double m = (double)a.n * a.h * a.w;
     const double cost_bytes = 4.0 * (m * a.cred + m * a.nout + 9.0 * a.cred * a.nout);   // X + Y + W
-    const double cost_flops = 18.0 * m * a.cred * a.nout;                                // of the convolution (the kernel executes 16/36 of them)
+    // flops EXECUTED on the MFMA pipe: 16 positions x (m / 4) tiles x 2 cred nout = 8 m cred nout -- 16/36 of the direct convolution's
+    // 18 m cred nout (bench.py reports that figure beside it as `direct_equivalent`; the roofline fraction uses the executed ones)
+    const double cost_flops = 8.0 * m * a.cred * a.nout;
     const int mtiles = a.n * a.tiles_h * a.tiles_w;
     const char* kname = ctx->timing ? ssdseg_intern(mode ? "conv3_wino_kernel [bwd_data]" : "conv3_wino_kernel [fwd]") : "";
     if (a.cs != nullptr || a.act != SSDSEG_ACT_NONE)
@@ -1468,7 +1470,7 @@ int conv3_wino_wgrad_launch(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, con
         configured = true;
     }
     const double cost_bytes = 4.0 * (m * cin + m * cout + 9.0 * cin * cout);   // X + dY + dW
-    const double cost_flops = 18.0 * m * cin * cout;                            // of the convolution (the kernel executes 16/36 of them)
+    const double cost_flops = 8.0 * m * cin * cout;                             // executed MFMA flops: 16/36 of the direct form's 18 m cin cout
     SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, conv3_wino_wgrad_kernel, dim3((unsigned)(patches * splits)), dim3(WWG_THREADS), WWG_LDS_BYTES, a);
     SSDSEG_LAUNCH_CHECK();
     const long long cn = (long long)cin * cout;

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Decoder 3x3 conv (304 -> 256 at 120x160, batch 32: the layer that is 45% of the full step) forward / input gradient / weight
 gradient in isolation, under the kernel switches of the environment.  usage: python scripts/conv3_decoder_time.py [reps] [batch] [cin] [cout]
-prints per kernel: launches, ms per launch, TFLOP/s by the convolution's flops; and a parity check against the direct kernels."""
+prints per kernel: launches, ms per launch, TFLOP/s by the flops the kernel executes (Winograd kernels: 16/36 of the direct
+convolution's; the direct-equivalent figure beside it); and a parity check against the direct kernels."""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "multi-task-learning-object-detection-semantic-segmentation_amd"))
@@ -37,7 +38,8 @@ ctx.sync()
 for name, r in ctx.timing_report().items():
     if r["count"]:
         ms = r["ms"] / r["count"]
-        print(f"{name[:60]:60s} x{r['count']:3d}  {ms:8.3f} ms/launch  {r['flops'] / r['count'] / ms / 1e9 if ms else 0:7.1f} TF")
+        tf = r['flops'] / r['count'] / ms / 1e9 if ms else 0
+        print(f"{name[:60]:60s} x{r['count']:3d}  {ms:8.3f} ms/launch  {tf:7.1f} TF" + (f"  ({tf * 2.25:6.1f} TF direct-equivalent)" if "wino" in name and tf else ""))
 ctx.timing(False)
 got = {"y": y.download(), "dx": dx.download(), "dw": dw.download(), "stats": stats.download().sum(0)}
 if os.environ.get("SSDSEG_CONV3_WINOGRAD", "") != "0":
