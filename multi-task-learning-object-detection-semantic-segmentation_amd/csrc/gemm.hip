@@ -840,6 +840,7 @@ int rowA_wn(int rows, int cols) { return pick_wn(cols, cdiv(rows, BM)); }
 #include "pw_tile.h"
 #include "conv3_wino.h"
 #include "conv3_wino_wgrad.h"
+#include "pw_wgrad.h"
 
 // ---- tile GEMM of the pointwise convs (pw_tile.h): shape -> (waves, column tile), launch
 // SSDSEG_PW_TILE: "0" never, "1" every shape the kernel takes, unset: where it measured faster
@@ -1178,8 +1179,79 @@ int launch_wgrad_wn(ssdseg_ctx* ctx, const WGradArgs& a, int wn, dim3 grid) {
     return 0;
 }
 
+// ---- pointwise weight gradient, row-naming form (pw_wgrad.h).  SSDSEG_PW_WGRAD=0: gemm_wgrad_kernel for everything.
+template <int JX, int JY, int WK, int WN>
+int pw_wgrad_launch(ssdseg_ctx* ctx, PwWgArgs a, float* dw) {
+    constexpr int G = 8 / (WK * WN), KT = 32 * JX * WK, NT = 32 * JY * WN, MS = pww_ms(KT, NT);
+    const int ktiles = cdiv(a.K, KT), ntiles = cdiv(a.N, NT);
+    const long long steps = ((long long)a.M + MS - 1) / MS;
+    // blocks: two per CU; every split >= 4 steps; partial slabs (splits * G * K * N, written and re-read) below half the operand traffic
+    long long splits = (2LL * ctx->num_cus + (long long)ktiles * ntiles - 1) / ((long long)ktiles * ntiles);
+    const long long cap_steps = (steps + 3) / 4;
+    const long long cap_traffic = (long long)((double)a.M * (a.K + a.N) / (2.0 * G * a.K * a.N));
+    if (splits > cap_steps) splits = cap_steps;
+    if (splits > cap_traffic) splits = cap_traffic;
+    if (splits < 1) splits = 1;
+    if (splits > 65535) splits = 65535;
+    const long long sps = (steps + splits - 1) / splits;
+    splits = (steps + sps - 1) / sps;
+    a.rows_per_split = (int)(sps * MS);
+    const long long slabs = splits * G;
+    const size_t pb = (size_t)slabs * a.K * a.N * sizeof(float);
+    if (pb >= ((size_t)1 << 31)) return -1;
+    float* part = dw;
+    if (slabs > 1) {
+        void* ws;
+        int rc = ssdseg_workspace(ctx, pb, &ws);
+        if (rc) return rc;
+        part = (float*)ws;
+    }
+    a.part = part;
+    a.part_bytes = (unsigned)pb;
+    const size_t lds = pww_lds_bytes(KT, NT);
+    const double cost_bytes = 4.0 * ((double)a.M * a.K + (double)a.M * a.N + (double)a.K * a.N);   // 8(d): read X, read dY, write dW
+    const double cost_flops = 2.0 * a.M * a.K * a.N;
+    ctx->timing_view_bytes = a.gs != nullptr ? 4.0 * a.M * a.N : 0.0;
+    char kbuf[64];
+    snprintf(kbuf, sizeof(kbuf), "pw_wgrad_kernel<%d, %d, %d, %d>", JX, JY, WK, WN);
+    const char* kname = ctx->timing ? ssdseg_intern(kbuf) : "";
+    SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (pw_wgrad_kernel<JX, JY, WK, WN>), dim3(ntiles, ktiles, (unsigned)splits), dim3(512), lds, a);
+    SSDSEG_LAUNCH_CHECK();
+    if (slabs > 1) return ssdseg_colsum(ctx, part, (int)slabs, (long long)a.K * a.N, dw);
+    return 0;
+}
+
+bool pw_wgrad_enabled() {
+    const char* e = getenv("SSDSEG_PW_WGRAD");
+    return !(e != nullptr && e[0] == '0');
+}
+
+// -> 0 launched, < 0 not taken (the caller falls back), > 0 error
+int pw_wgrad_try(ssdseg_ctx* ctx, const WGradArgs& w, float* dw) {
+    if (!pw_wgrad_enabled() || w.stem || w.convH > 0 || w.K % 4 != 0 || w.N % 4 != 0 || w.ldx % 4 != 0 || w.ldy % 4 != 0) return -1;
+    if ((long long)w.M * w.ldx * 4 >= (1LL << 31) || (long long)w.M * w.ldy * 4 >= (1LL << 31)) return -1;
+    PwWgArgs a{};
+    a.x = w.x; a.xs = w.xs; a.xt = w.xt; a.xact = w.xact; a.ldx = w.ldx;
+    a.g = w.g; a.y = w.y; a.gs = w.gs; a.gt = w.gt; a.gk1 = w.gk1; a.gk0 = w.gk0; a.gact = w.gact; a.ldy = w.ldy;
+    a.M = w.M; a.K = w.K; a.N = w.N;
+    a.x_bytes = (unsigned)((((long long)w.M - 1) * w.ldx + w.K) * 4);
+    a.g_bytes = (unsigned)((((long long)w.M - 1) * w.ldy + w.N) * 4);
+    const int k = w.K, n = w.N;
+    // tile = (32 JX WK) x (32 JY WN): the smallest one that covers the layer's channels, else the 256 x 128 / 128 x 256 block tiles
+    int rc;
+    if (k <= 32) rc = n <= 32 ? pw_wgrad_launch<1, 1, 1, 1>(ctx, a, dw) : (n <= 64 ? pw_wgrad_launch<1, 2, 1, 1>(ctx, a, dw) : pw_wgrad_launch<1, 4, 1, 1>(ctx, a, dw));
+    else if (k <= 64) rc = n <= 32 ? pw_wgrad_launch<2, 1, 1, 1>(ctx, a, dw) : (n <= 64 ? pw_wgrad_launch<2, 2, 1, 1>(ctx, a, dw) : pw_wgrad_launch<2, 2, 1, 2>(ctx, a, dw));
+    else if (k <= 128) rc = n <= 32 ? pw_wgrad_launch<4, 1, 1, 1>(ctx, a, dw) : (n <= 64 ? pw_wgrad_launch<2, 2, 2, 1>(ctx, a, dw) : (n <= 128 ? pw_wgrad_launch<2, 2, 2, 2>(ctx, a, dw) : pw_wgrad_launch<2, 2, 2, 4>(ctx, a, dw)));
+    else rc = n <= 32 ? pw_wgrad_launch<4, 1, 2, 1>(ctx, a, dw) : (n <= 64 ? pw_wgrad_launch<2, 2, 4, 1>(ctx, a, dw) : pw_wgrad_launch<2, 2, 4, 2>(ctx, a, dw));
+    return rc;
+}
+
 // picks the tile shape / split count for dw[k][n] = sum_m x[m][k]*dy[m][n], launches, reduces the split partials
 int wgrad_run(ssdseg_ctx* ctx, WGradArgs a, float* dw) {
+    {
+        const int rc = pw_wgrad_try(ctx, a, dw);
+        if (rc >= 0) return rc;
+    }
     const int m = a.M, k = a.K, n = a.N;
     const int wi = k <= 32 ? 1 : (k <= 64 ? 2 : 4);
     const int wr = 4 / wi;
