@@ -247,6 +247,9 @@ def pmc_traffic(kernel: str, workload: str, batch: int):
         return None, None
     key = kernel.strip("()")
     row = kernels.get(key)
+    if row is None and " [" in key:
+        # the library labels some launches by role ("conv3_wino_kernel<true> [fwd]"); rocprofv3 knows the bare symbol
+        row = kernels.get(key.split(" [")[0])
     if row is None:
         return None, None
     return round(row["hbm_bytes_per_launch"], 1), os.path.relpath(files[-1], here)

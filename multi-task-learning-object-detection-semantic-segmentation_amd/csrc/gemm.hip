@@ -1491,8 +1491,11 @@ int conv3_wino_launch(ssdseg_ctx* ctx, Conv3TArgs a, const float* w, int cin, in
     // 18 m cred nout (bench.py reports that figure beside it as `direct_equivalent`; the roofline fraction uses the executed ones)
     const double cost_flops = 8.0 * m * a.cred * a.nout;
     const int mtiles = a.n * a.tiles_h * a.tiles_w;
-    const char* kname = ctx->timing ? ssdseg_intern(mode ? "conv3_wino_kernel [bwd_data]" : "conv3_wino_kernel [fwd]") : "";
-    if (a.cs != nullptr || a.act != SSDSEG_ACT_NONE)
+    const bool with_view = a.cs != nullptr || a.act != SSDSEG_ACT_NONE;
+    char kbuf[64];
+    snprintf(kbuf, sizeof(kbuf), "conv3_wino_kernel<%s> [%s]", with_view ? "true" : "false", mode ? "bwd_data" : "fwd");   // symbol as rocprofv3 spells it + role
+    const char* kname = ctx->timing ? ssdseg_intern(kbuf) : "";
+    if (with_view)
         SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, conv3_wino_kernel<true>, dim3((unsigned)(mtiles * a.ntiles_n)), dim3(C3T_THREADS), lds, a);
     else
         SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, conv3_wino_kernel<false>, dim3((unsigned)(mtiles * a.ntiles_n)), dim3(C3T_THREADS), lds, a);
