@@ -2,6 +2,7 @@
 // Keras BatchNormalization: axis -1, eps 1e-3, momentum 0.99 (reference models.py:66,89,111; blocks.py:29,...;
 // semantics SURVEY.md App. B.3).  All reductions are two-level with a fixed summation order (deterministic).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -294,7 +295,10 @@ int ssdseg_bn_bwd_finalize_launch(ssdseg_ctx* ctx, const float* part, int nparts
 }
 
 int ssdseg_colsum(ssdseg_ctx* ctx, const float* part, int nparts, long long len, float* out) {
-    const int rc = reduce_rc(nparts, len);
+    // wide tables (weight-gradient slabs: thousands of columns) fill the chip with 32-column blocks as well, and those read whole
+    // 128-byte lines of every partial row instead of 32-byte pieces (SSDSEG_COLSUM_RC=8 restores the narrow blocks for A/B runs)
+    const char* e = getenv("SSDSEG_COLSUM_RC");
+    const int rc = (len >= 4096 && !(e != nullptr && e[0] == '8')) ? 32 : reduce_rc(nparts, len);
     const dim3 grid(cdiv(len, rc)), block(rc, RTHREADS / rc);
     if (rc == 2) SSDSEG_LAUNCH_NAMED(ctx, "colsum_kernel", 4.0 * nparts * len, 0.0, colsum_kernel<2>, grid, block, 0, part, nparts, (int)len, out);
     else if (rc == 8) SSDSEG_LAUNCH_NAMED(ctx, "colsum_kernel", 4.0 * nparts * len, 0.0, colsum_kernel<8>, grid, block, 0, part, nparts, (int)len, out);

@@ -1185,10 +1185,10 @@ int pw_wgrad_launch(ssdseg_ctx* ctx, PwWgArgs a, float* dw) {
     constexpr int G = 8 / (WK * WN), KT = 32 * JX * WK, NT = 32 * JY * WN, MS = pww_ms(KT, NT);
     const int ktiles = cdiv(a.K, KT), ntiles = cdiv(a.N, NT);
     const long long steps = ((long long)a.M + MS - 1) / MS;
-    // blocks: two per CU; every split >= 4 steps; partial slabs (splits * G * K * N, written and re-read) below half the operand traffic
+    // blocks: two per CU; every split >= 4 steps; partial slabs (splits * K * N, written and re-read) below half the operand traffic
     long long splits = (2LL * ctx->num_cus + (long long)ktiles * ntiles - 1) / ((long long)ktiles * ntiles);
     const long long cap_steps = (steps + 3) / 4;
-    const long long cap_traffic = (long long)((double)a.M * (a.K + a.N) / (2.0 * G * a.K * a.N));
+    const long long cap_traffic = (long long)((double)a.M * (a.K + a.N) / (2.0 * a.K * a.N));
     if (splits > cap_steps) splits = cap_steps;
     if (splits > cap_traffic) splits = cap_traffic;
     if (splits < 1) splits = 1;
@@ -1196,7 +1196,7 @@ int pw_wgrad_launch(ssdseg_ctx* ctx, PwWgArgs a, float* dw) {
     const long long sps = (steps + splits - 1) / splits;
     splits = (steps + sps - 1) / sps;
     a.rows_per_split = (int)(sps * MS);
-    const long long slabs = splits * G;
+    const long long slabs = splits;
     const size_t pb = (size_t)slabs * a.K * a.N * sizeof(float);
     if (pb >= ((size_t)1 << 31)) return -1;
     float* part = dw;
@@ -1208,7 +1208,12 @@ int pw_wgrad_launch(ssdseg_ctx* ctx, PwWgArgs a, float* dw) {
     }
     a.part = part;
     a.part_bytes = (unsigned)pb;
-    const size_t lds = pww_lds_bytes(KT, NT);
+    const size_t lds = pww_lds_bytes(KT, NT, G);
+    static bool configured = false;      // (per instantiation) dynamic LDS beyond 64 KiB has to be announced once
+    if (lds > 64 * 1024 && !configured) {
+        SSDSEG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_wgrad_kernel<JX, JY, WK, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = true;
+    }
     const double cost_bytes = 4.0 * ((double)a.M * a.K + (double)a.M * a.N + (double)a.K * a.N);   // 8(d): read X, read dY, write dW
     const double cost_flops = 2.0 * a.M * a.K * a.N;
     ctx->timing_view_bytes = a.gs != nullptr ? 4.0 * a.M * a.N : 0.0;

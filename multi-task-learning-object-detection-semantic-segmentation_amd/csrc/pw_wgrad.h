@@ -10,8 +10,8 @@
 // where MFMA row r MEANS input channel JX r + jx and column r' MEANS output channel JY r' + jy; the instruction's two k-slots
 // are the two pixels of the pair.  Block = eight waves = (G row groups) x (WK x WN wave tiles of 32 JX x 32 JY): wide layers
 // use G = 1 and a 256 x 128 / 128 x 256 block tile, narrow ones a tile that covers ALL their channels (each operand element
-// is then read from HBM exactly once) with the eight waves splitting the pixels; every (split, group) writes its own partial
-// slab, the fixed-order column sum (ssdseg_colsum) adds them.
+// is then read from HBM exactly once) with the eight waves splitting the pixels (their partial tiles are folded through LDS in a
+// fixed order at the end); every split writes its own partial slab, the fixed-order column sum (ssdseg_colsum) adds them.
 // Staging: raw buffer loads (32-bit offsets, hardware range check) one step ahead, views applied once per element while
 // committing to LDS ([pixel][channel], the natural layout: no swizzle needed -- a wave's read is one contiguous run), two LDS
 // buffers, one barrier per step.  Rows past the end of a split are zeroed on the dy side only (a zero factor is enough).
@@ -29,7 +29,7 @@ struct PwWgArgs {
     const float* gk1;
     const float* gk0;
     int gact, ldy;
-    float* part;         // [splits * G][K][N]
+    float* part;         // [splits][K][N]
     int M, K, N;
     int rows_per_split;  // multiple of the step's rows
     unsigned x_bytes, g_bytes, part_bytes;
@@ -43,7 +43,11 @@ template <int N> __device__ __forceinline__ float pww_comp(const typename pww_ve
 template <> __device__ __forceinline__ float pww_comp<1>(const float& v, int) { return v; }
 
 constexpr int pww_ms(int kt, int nt) { return (kt + nt) > 256 ? 16 : ((kt + nt) > 128 ? 32 : 64); }     // rows per step: <= 24 KB per buffer
-constexpr size_t pww_lds_bytes(int kt, int nt) { return (2 * (size_t)pww_ms(kt, nt) * (kt + nt) + 2 * (size_t)kt + 4 * (size_t)nt) * sizeof(float); }
+constexpr size_t pww_lds_bytes(int kt, int nt, int g) {
+    const size_t loop = (2 * (size_t)pww_ms(kt, nt) * (kt + nt) + 2 * (size_t)kt + 4 * (size_t)nt) * sizeof(float);
+    const size_t fold = g > 1 ? (size_t)(g / 2) * kt * nt * sizeof(float) : 0;      // the upper half of the row groups parks its tile
+    return loop > fold ? loop : fold;
+}
 
 template <int JX, int JY, int WK, int WN>
 __global__ void __launch_bounds__(512, 2) pw_wgrad_kernel(PwWgArgs p) {
@@ -197,12 +201,43 @@ __global__ void __launch_bounds__(512, 2) pw_wgrad_kernel(PwWgArgs p) {
         cur ^= 1;
     }
 
-    // ---- partial slab (split * G + grp).  C/D layout: column = lane & 31 (group r' of output channels), row = (e & 3) + 8 * (e >> 2) + 4 * kk
+    // ---- the G row groups of the block hold partial sums of the SAME tile: fold them through LDS in log2(G) rounds (upper half
+    // writes, lower half adds: a fixed order), so that a block leaves ONE slab -- the column sum over the slabs reads G times less
+    if (G > 1) {
+        constexpr int WT = JX * JY * 16 * 64;                  // floats of one wave's accumulators
+        const int wpos = wk * WN + wn;
+#pragma unroll
+        for (int h = G / 2; h >= 1; h >>= 1) {
+            __syncthreads();                                    // the operand buffers (first round) / the previous round's slots are free
+            if (grp >= h && grp < 2 * h) {
+                float* dst = smem + ((grp - h) * (WK * WN) + wpos) * WT + lane;
+#pragma unroll
+                for (int a = 0; a < JX; ++a)
+#pragma unroll
+                    for (int b = 0; b < JY; ++b)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) dst[((a * JY + b) * 16 + e) * 64] = acc[a][b][e];
+            }
+            __syncthreads();
+            if (grp < h) {
+                const float* src = smem + (grp * (WK * WN) + wpos) * WT + lane;
+#pragma unroll
+                for (int a = 0; a < JX; ++a)
+#pragma unroll
+                    for (int b = 0; b < JY; ++b)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[a][b][e] += src[((a * JY + b) * 16 + e) * 64];
+            }
+        }
+        if (grp != 0) return;
+    }
+
+    // ---- partial slab of this split.  C/D layout: column = lane & 31 (group r' of output channels), row = (e & 3) + 8 * (e >> 2) + 4 * kk
     // (group r of input channels): element (k, n) = (kw0 + JX row + a, nw0 + JY col + b); a lane's JY outputs are adjacent in memory.
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(p.part, 0, p.part_bytes, 0x00020000);
     const int kw0 = k0 + wk * 32 * JX, nw0 = n0 + wn * 32 * JY;
     const int nn = nw0 + JY * r;
-    const int slab = (split * G + grp) * p.K;
+    const int slab = split * p.K;
     const unsigned lane_off = (unsigned)(((long long)(slab + kw0 + 4 * JX * kk) * p.N + nn) * 4);
     const int krow = kw0 + 4 * JX * kk;
 #pragma unroll
