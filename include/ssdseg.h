@@ -220,6 +220,16 @@ int ssdseg_pwconv_bwd_bn(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const 
 int ssdseg_conv3x3_parts(int n, int h, int w, int cin, int cout, int* nparts_host);
 int ssdseg_conv3x3_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const float* w, float* y, int n, int h,
                        int wdt, int cin, int cout, float* stats);
+/* Large layers (the DeepLabV3+ decoder conv) run in the Winograd form, whose weight gradient wants the ACTIVATED input act(scale*x+shift)
+ * in a zero-bordered copy [n][h+2][w+2][cin].  ssdseg_conv3x3_saved_floats reports that copy's size for a shape (0: the shape does
+ * not use it -- call the plain entry points); ssdseg_conv3x3_fwd_saved writes it (one pass; the forward kernel then reads IT, with
+ * the identity view) and ssdseg_conv3x3_bwd_weight_saved consumes it, so the view is applied once per step instead of twice.
+ * Same results as ssdseg_conv3x3_fwd / _bwd_weight (dy: the materialised gradient, i.e. an identity gradient view). */
+int ssdseg_conv3x3_saved_floats(int n, int h, int w, int cin, int cout, long long* floats_host);
+int ssdseg_conv3x3_fwd_saved(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const float* w, float* y, int n, int h, int wdt, int cin,
+                             int cout, float* stats, float* xsaved);
+int ssdseg_conv3x3_bwd_weight_saved(ssdseg_ctx* ctx, const float* xsaved, const float* dy, float* dw, int n, int h, int wdt, int cin,
+                                    int cout);
 int ssdseg_conv3x3_bwd_data(ssdseg_ctx* ctx, const ssdseg_gview* dy, const float* w, float* dx, int ldx, int n,
                             int h, int wdt, int cin, int cout, int accumulate);
 int ssdseg_conv3x3_bwd_weight(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssdseg_gview* dy, float* dw,

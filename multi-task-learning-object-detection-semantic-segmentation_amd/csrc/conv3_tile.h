@@ -46,6 +46,7 @@ struct Conv3TArgs {
     int ncols;           // output channels per column tile (<= 32*WN)
     int flip;            // backward: patch tap t uses the weights of tap 8 - t
     unsigned in_bytes, wt_bytes;   // extents for the buffer descriptors (both < 2^31)
+    int in_hp, in_wp;              // conv3_wino_kernel only: rows per image / pixels per row of the INPUT buffer (h, w; h+2, w+2 for the zero-bordered copy)
 };
 
 constexpr size_t conv3t_lds_floats(int wn, int cred) { return 2 * (size_t)(C3T_PATCH_F + 9 * 32 * wn * C3T_KC) + 2 * (size_t)cred; }

@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(C3T_THREADS, 2) conv3_wino_kernel(Conv3TArgs p
         const int prow = pix / C3T_PW, pcol = pix - prow * C3T_PW;
         const int gh = h0 - 1 + prow, gw = w0 - 1 + pcol;
         const bool ok = slot < PSLOTS && gh >= 0 && gh < p.h && gw >= 0 && gw < p.w;
-        pgo[q] = ok ? (unsigned)(((((long long)img * p.h + gh) * p.w + gw) * p.ldi + 4 * chunk) * 4) : OOB;
+        pgo[q] = ok ? (unsigned)(((((long long)img * p.in_hp + gh) * p.in_wp + gw) * p.ldi + 4 * chunk) * 4) : OOB;
         // a thread without a second slot writes to the four spare pixels at the end of the plane: the stores stay unconditional
         // (a branch around them would also skip the load's s_waitcnt, and the compiler would re-insert it -- counting the DMAs -- later)
         plo[q] = slot < PSLOTS ? raw_off(prow, pcol, chunk) : (chunk * WINO_PIXP + C3T_PIX + (t & 3)) * 4;

@@ -1481,7 +1481,9 @@ int conv3_wino_launch(ssdseg_ctx* ctx, Conv3TArgs a, const float* w, int cin, in
     SSDSEG_LAUNCH_CHECK();
     a.wt = (const float*)ws;
     a.tiles_h = cdiv(a.h, C3T_ROWS); a.tiles_w = cdiv(a.w, C3T_COLS); a.ntiles_n = cdiv(a.nout, WINO_NT); a.ncols = WINO_NT;
-    a.in_bytes = (unsigned)((((long long)a.n * a.h * a.w - 1) * a.ldi + a.cred) * 4);
+    if (a.in_hp == 0) { a.in_hp = a.h; a.in_wp = a.w; }
+    // (the zero-bordered copy is entered at its pixel (1, 1): the last byte the kernel may touch is that of image pixel (h-1, w-1))
+    a.in_bytes = (unsigned)(((((long long)(a.n - 1) * a.in_hp + a.h - 1) * a.in_wp + a.w - 1) * a.ldi + a.cred) * 4);
     a.wt_bytes = (unsigned)ubytes;
     const size_t lds = wino_lds_floats(a.cred) * sizeof(float);
     static size_t configured = 0;
@@ -1516,7 +1518,9 @@ bool conv3_wino_wgrad_takes(int n, int h, int w, int cin, int cout) {
     return mode == 1 || (long long)n * (h / 2) * (w / 32) >= 512;
 }
 
-int conv3_wino_wgrad_launch(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const float* dy, float* dw, int n, int h, int w, int cin, int cout) {
+// xsaved != nullptr: the zero-bordered activated input already exists (written by ssdseg_conv3x3_fwd_saved), `in` is not read
+int conv3_wino_wgrad_launch(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const float* dy, float* dw, int n, int h, int w, int cin, int cout,
+                            const float* xsaved = nullptr) {
     WinoWgArgs a{};
     a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout;
     a.cpatches = cdiv(cin, WWG_KT); a.npatches = cdiv(cout, WWG_NT);
@@ -1528,22 +1532,24 @@ int conv3_wino_wgrad_launch(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, con
     if (splits < 1) splits = 1;
     a.steps_per_split = (a.steps + splits - 1) / splits;
     splits = (a.steps + a.steps_per_split - 1) / a.steps_per_split;
-    const size_t xpb = align256((size_t)n * (h + 2) * (w + 2) * cin * sizeof(float));
+    const size_t xpb = xsaved != nullptr ? 0 : align256((size_t)n * (h + 2) * (w + 2) * cin * sizeof(float));
     const size_t pb = (size_t)splits * 16 * cin * cout * sizeof(float);
     SSDSEG_ARG(pb < ((size_t)1 << 31), 9);
     void* ws;
     int rc = ssdseg_workspace(ctx, xpb + pb, &ws);
     if (rc) return rc;
     float* xp = (float*)ws;
-    a.xp = xp; a.dy = dy; a.part = (float*)((char*)ws + xpb);
+    a.xp = xsaved != nullptr ? xsaved : xp; a.dy = dy; a.part = (float*)((char*)ws + xpb);
     a.xp_bytes = (unsigned)((size_t)n * (h + 2) * (w + 2) * cin * sizeof(float));
     a.dy_bytes = (unsigned)((size_t)n * h * w * cout * sizeof(float));
     a.part_bytes = (unsigned)pb;
     const double m = (double)n * h * w;
-    const long long tot4 = (long long)n * (h + 2) * (w + 2) * (cin / 4);
-    SSDSEG_LAUNCH(ctx, 8.0 * m * cin, 0.0, conv3_pad_view_kernel, dim3((unsigned)((tot4 + 255) / 256 < 16384 ? (tot4 + 255) / 256 : 16384)), dim3(256), 0, in->x,
-                  in->scale, in->shift, in->act, ldx, xp, n, h, w, cin);
-    SSDSEG_LAUNCH_CHECK();
+    if (xsaved == nullptr) {
+        const long long tot4 = (long long)n * (h + 2) * (w + 2) * (cin / 4);
+        SSDSEG_LAUNCH(ctx, 8.0 * m * cin, 0.0, conv3_pad_view_kernel, dim3((unsigned)((tot4 + 255) / 256 < 16384 ? (tot4 + 255) / 256 : 16384)), dim3(256), 0, in->x,
+                      in->scale, in->shift, in->act, ldx, xp, n, h, w, cin);
+        SSDSEG_LAUNCH_CHECK();
+    }
     static bool configured = false;   // dynamic LDS beyond 64 KiB has to be announced once
     if (!configured) {
         SSDSEG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wino_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WWG_LDS_BYTES));
@@ -2009,6 +2015,56 @@ int ssdseg_conv3x3_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const fl
     a.I = n * h * wdt; a.R = 9 * cin; a.J = cout;
     a.convH = h; a.convW = wdt; a.convC = cin; a.convSign = 1;
     return launch_rowA<0, 1>(ctx, a);
+}
+
+// ---- forward that SAVES its activated input for the weight gradient (large Winograd layers; include/ssdseg.h)
+int ssdseg_conv3x3_saved_floats(int n, int h, int w, int cin, int cout, long long* floats_host) {
+    SSDSEG_ARG(n > 0 && h > 0 && w > 0, 1);
+    SSDSEG_ARG(cin > 0 && cin % 4 == 0, 4);
+    SSDSEG_ARG(cout > 0 && cout % 4 == 0, 5);
+    SSDSEG_ARG(floats_host != nullptr, 6);
+    const bool both = !conv3_narrow(cin, cout) && getenv("SSDSEG_CONV3_WGRAD") == nullptr && getenv("SSDSEG_CONV3_SAVED") == nullptr &&
+                      conv3_wino_takes(n, h, w, cin, cout) && conv3_wino_wgrad_takes(n, h, w, cin, cout);
+    *floats_host = both ? (long long)n * (h + 2) * (w + 2) * cin : 0;
+    return 0;
+}
+
+int ssdseg_conv3x3_fwd_saved(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const float* w, float* y, int n, int h, int wdt, int cin, int cout,
+                             float* stats, float* xsaved) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(in != nullptr && in->x != nullptr && ((in->scale == nullptr) == (in->shift == nullptr)), 2);
+    SSDSEG_ARG(ldx >= cin && ldx % 4 == 0, 3);
+    SSDSEG_ARG(w != nullptr, 4);
+    SSDSEG_ARG(y != nullptr, 5);
+    SSDSEG_ARG(xsaved != nullptr, 12);
+    long long need = 0;
+    int rc = ssdseg_conv3x3_saved_floats(n, h, wdt, cin, cout, &need);
+    if (rc) return rc;
+    SSDSEG_ARG(need > 0, 6);     // only for shapes ssdseg_conv3x3_saved_floats reports a size for
+    const long long tot4 = (long long)n * (h + 2) * (wdt + 2) * (cin / 4);
+    SSDSEG_LAUNCH(ctx, 8.0 * n * h * wdt * cin, 0.0, conv3_pad_view_kernel, dim3((unsigned)((tot4 + 255) / 256 < 16384 ? (tot4 + 255) / 256 : 16384)), dim3(256), 0,
+                  in->x, in->scale, in->shift, in->act, ldx, xsaved, n, h, wdt, cin);
+    SSDSEG_LAUNCH_CHECK();
+    Conv3TArgs t{};
+    t.in = xsaved + ((long long)(wdt + 2) + 1) * cin;      // pixel (1, 1) of image 0 of the zero-bordered copy
+    t.act = SSDSEG_ACT_NONE; t.ldi = cin;
+    t.in_hp = h + 2; t.in_wp = wdt + 2;
+    t.out = y; t.ldo = cout; t.accumulate = 0;
+    t.stats = stats;
+    t.n = n; t.h = h; t.w = wdt; t.cred = cin; t.nout = cout; t.flip = 0;
+    return conv3_wino_launch(ctx, t, w, cin, cout, 0);
+}
+
+int ssdseg_conv3x3_bwd_weight_saved(ssdseg_ctx* ctx, const float* xsaved, const float* dy, float* dw, int n, int h, int wdt, int cin, int cout) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(xsaved != nullptr, 2);
+    SSDSEG_ARG(dy != nullptr, 3);
+    SSDSEG_ARG(dw != nullptr, 4);
+    long long need = 0;
+    int rc = ssdseg_conv3x3_saved_floats(n, h, wdt, cin, cout, &need);
+    if (rc) return rc;
+    SSDSEG_ARG(need > 0, 5);
+    return conv3_wino_wgrad_launch(ctx, nullptr, cin, dy, dw, n, h, wdt, cin, cout, xsaved);
 }
 
 int ssdseg_conv3x3_bwd_data(ssdseg_ctx* ctx, const ssdseg_gview* dy, const float* w, float* dx, int ldx, int n, int h, int wdt,

@@ -284,9 +284,21 @@ class Conv3Op(Op):
             out.stats = eng.ctx.empty((out.nparts, 2, out.c))
         assert out.ld == out.c
         self.out_val: Optional[Val] = None
+        # large layers (Winograd kernels): the forward leaves act(BN(x)) in a zero-bordered copy which the weight gradient reads
+        # again, so the view is applied once per step (ssdseg_conv3x3_fwd_saved / _bwd_weight_saved)
+        self.xsaved = None
+        if eng.training:
+            need = C.c_longlong()
+            H._check(eng.ctx.lib.ssdseg_conv3x3_saved_floats(s.n, s.h, s.w, s.c, out.c, C.byref(need)), "ssdseg_conv3x3_saved_floats")
+            if need.value > 0:
+                self.xsaved = eng.ctx.empty(need.value)
 
     def fwd(self):
         s = self.inp.store
+        if self.xsaved is not None:
+            self.e.ctx.call("ssdseg_conv3x3_fwd_saved", self.inp.view(), s.ld, self.w, self.out.buf, s.n, s.h, s.w, s.c, self.out.c, self.out.stats,
+                            self.xsaved)
+            return
         self.e.ctx.call("ssdseg_conv3x3_fwd", self.inp.view(), s.ld, self.w, self.out.buf, s.n, s.h, s.w, s.c, self.out.c, self.out.stats)
 
     def bwd(self):
@@ -305,7 +317,10 @@ class Conv3Op(Op):
         if side:
             self.e.ctx.side(True)
         try:
-            self.e.ctx.call("ssdseg_conv3x3_bwd_weight", self.inp.view(), s.ld, gv, self.dw, s.n, s.h, s.w, s.c, self.out.c)
+            if self.xsaved is not None and self.out_val.bn is not None:     # (materialised dy: the saved-input weight gradient's form)
+                self.e.ctx.call("ssdseg_conv3x3_bwd_weight_saved", self.xsaved, self.out.grad, self.dw, s.n, s.h, s.w, s.c, self.out.c)
+            else:
+                self.e.ctx.call("ssdseg_conv3x3_bwd_weight", self.inp.view(), s.ld, gv, self.dw, s.n, s.h, s.w, s.c, self.out.c)
         finally:
             if side:
                 self.e.ctx.side(False)

@@ -90,6 +90,9 @@ _SIGNATURES = {
     "ssdseg_pwconv_bwd_bn": [_vp, _VP, _i, _GP, _i, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "ssdseg_conv3x3_parts": [_i, _i, _i, _i, _i, _ip],
     "ssdseg_conv3x3_fwd": [_vp, _VP, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "ssdseg_conv3x3_saved_floats": [_i, _i, _i, _i, _i, C.POINTER(C.c_longlong)],
+    "ssdseg_conv3x3_fwd_saved": [_vp, _VP, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "ssdseg_conv3x3_bwd_weight_saved": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i],
     "ssdseg_conv3x3_bwd_data": [_vp, _GP, _vp, _vp, _i, _i, _i, _i, _i, _i, _i],
     "ssdseg_conv3x3_bwd_weight": [_vp, _VP, _i, _GP, _vp, _i, _i, _i, _i, _i],
     "ssdseg_bn_finalize": [_vp, _vp, _i, _i, _d, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i],

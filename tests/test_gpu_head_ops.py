@@ -362,3 +362,45 @@ def test_maxpool_shuffle_actbwd_dice(ctx, rng):
         loss = ctx.empty(n)
         ctx.call("ssdseg_dice_loss", ctx.array(y), ctx.array(p), n, 300, 4, (C.c_float * 4)(*cw), sq, loss)
         assert rel_err(loss.download(), O.dice_loss(y[:, :, None], p[:, :, None], cw, bool(sq))) < 1e-5
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 6, 64, 80, 72), (1, 16, 32, 304, 256)])
+def test_conv3x3_saved_input_pair_equals_plain_entry_points(ctx, rng, monkeypatch, n, h, w, cin, cout):
+    """ssdseg_conv3x3_fwd_saved / _bwd_weight_saved (the forward leaves act(BN(x)) in a zero-bordered copy, the Winograd weight
+    gradient reads it again): same outputs, BatchNorm partial sums and weight gradient as the plain entry points, and the oracle's"""
+    import ctypes as C
+    from ssdseglib import _hip as H
+    monkeypatch.setenv("SSDSEG_CONV3_WINOGRAD", "1")
+    monkeypatch.setenv("SSDSEG_CONV3_NARROW", "0")
+    act = O.ACT_RELU6
+    x, sc, sh, a = view_inputs(rng, (n, h, w, cin), act)
+    wgt = (rng.normal(0, 1, (3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+    dy = rng.normal(0, 1, (n, h, w, cout)).astype(np.float32)
+    need = C.c_longlong()
+    assert ctx.lib.ssdseg_conv3x3_saved_floats(n, h, w, cin, cout, C.byref(need)) == 0
+    assert need.value == n * (h + 2) * (w + 2) * cin
+    dx_, dsc, dsh, dw_, ddy = ctx.array(x), ctx.array(sc), ctx.array(sh), ctx.array(wgt), ctx.array(dy)
+    nparts = ctx.parts("ssdseg_conv3x3_parts", n, h, w, cin, cout)
+    y0, y1 = ctx.empty((n, h, w, cout)), ctx.empty((n, h, w, cout))
+    st0, st1 = ctx.empty((nparts, 2, cout)), ctx.empty((nparts, 2, cout))
+    g0, g1 = ctx.empty(wgt.shape), ctx.empty(wgt.shape)
+    xs = ctx.empty(need.value)
+    xs.upload(np.full(need.value, np.nan, np.float32))                       # every element, borders included, must be written
+    ctx.call("ssdseg_conv3x3_fwd", H.view(dx_, dsc, dsh, act), cin, dw_, y0, n, h, w, cin, cout, st0)
+    ctx.call("ssdseg_conv3x3_fwd_saved", H.view(dx_, dsc, dsh, act), cin, dw_, y1, n, h, w, cin, cout, st1, xs)
+    saved = xs.download().reshape(n, h + 2, w + 2, cin)
+    assert np.abs(saved[:, 1:-1, 1:-1] - a).max() < 2e-6 * np.abs(a).max()   # act(scale * x + shift) (one fma on the device, mul + add in NumPy)
+    assert not saved[:, 0].any() and not saved[:, -1].any() and not saved[:, :, 0].any() and not saved[:, :, -1].any()
+    y_ref = O.conv2d_fwd(a.astype(np.float64), wgt.astype(np.float64))
+    assert rel_err(y1.download(), y_ref) < 2e-5
+    assert rel_err(y1.download(), y0.download().astype(np.float64)) < 5e-6   # view applied before vs while staging: same values, same sums
+    assert rel_err(st1.download().sum(0), st0.download().sum(0).astype(np.float64)) < 1e-5
+    ctx.call("ssdseg_conv3x3_bwd_weight", H.view(dx_, dsc, dsh, act), cin, H.gview(ddy), g0, n, h, w, cin, cout)
+    ctx.call("ssdseg_conv3x3_bwd_weight_saved", xs, ddy, g1, n, h, w, cin, cout)
+    np.testing.assert_array_equal(g1.download(), g0.download())              # the same kernel on the same padded tensor
+    _, dw_ref, _ = O.conv2d_bwd(a.astype(np.float64), wgt.astype(np.float64), dy.astype(np.float64))
+    assert rel_err(g1.download(), dw_ref) < 5e-5
+    # a shape the Winograd pair does not take reports no saved tensor and refuses the call
+    assert ctx.lib.ssdseg_conv3x3_saved_floats(1, 5, 5, 24, 8, C.byref(need)) == 0 and need.value == 0
+    with pytest.raises(H.SsdsegError):
+        ctx.call("ssdseg_conv3x3_fwd_saved", H.view(dx_), 24, dw_, y1, 1, 5, 5, 24, 8, None, xs)
