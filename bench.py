@@ -319,6 +319,7 @@ def main():
     ap.add_argument("--workload", default="full", choices=["backbone", "full", "shufflenet"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events in the timed region")
+    ap.add_argument("--all-kernels", action="store_true", help="list every kernel symbol of the survey step (default: the 16 heaviest)")
     args = ap.parse_args()
 
     from ssdseglib import _hip as H
@@ -463,7 +464,7 @@ def main():
                 out["roofline_depthwise_bwd"] = {"kernel": dwk[0], "bound": "hbm", "achieved": round(g, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                  "frac": round(g / HBM_PEAK_GBS, 4), "launches": dwk[1]["count"], "avg_launch_ms": round(a, 4),
                                                  "note": "survey step (isolated); bytes = 4(2X+Y+18C) per SURVEY.md 8(d)"}
-            top = sorted(survey.items(), key=lambda kv: -kv[1]["ms"])[:16]
+            top = sorted(survey.items(), key=lambda kv: -kv[1]["ms"])[:(None if args.all_kernels else 16)]
             out["kernels_survey_step"] = [
                 {"kernel": k, "launches": v["count"], "ms_per_step": round(v["ms"], 4),
                  "GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0.0,

@@ -161,8 +161,9 @@ def test_bilinear(ctx, rng, n, h, w, c, fy, fx):
     assert np.all(got[:, :4] == 0) and np.all(got[:, 4 + c:] == 0)
 
 
-def test_mask_head(ctx, rng):
-    n, h, w, c, f = 2, 12, 16, 4, 4
+@pytest.mark.parametrize("n,h,w", [(2, 12, 16), (1, 17, 35), (3, 5, 3)])     # whole 16x16 tiles; ragged tiles; smaller than one tile
+def test_mask_head(ctx, rng, monkeypatch, n, h, w):
+    c, f = 4, 4
     logits = rng.normal(0, 2, (n, h, w, c)).astype(np.float32)
     cls = rng.integers(0, c, (n, h * f, w * f))
     y = np.eye(c, dtype=np.float32)[cls]
@@ -182,6 +183,12 @@ def test_mask_head(ctx, rng):
     g = ctx.empty(logits.shape)
     ctx.call("ssdseg_mask_head_bwd", dl, n, h, w, c, f, f, dy, cwh, 0.5, g)
     assert rel_err(g.download(), dlogits_ref) < 2e-5
+    # the tile kernel (default for x4) computes every full-resolution dz once per block and walks each window in the order of the
+    # one-thread-per-pixel kernel: bit-identical
+    tile = g.download()
+    monkeypatch.setenv("SSDSEG_MASK_BWD", "gather")
+    ctx.call("ssdseg_mask_head_bwd", dl, n, h, w, c, f, f, dy, cwh, 0.5, g)
+    np.testing.assert_array_equal(g.download(), tile)
 
 
 def test_head_gather_and_softmax(ctx, rng):
