@@ -151,6 +151,70 @@ __global__ void bilinear_fwd_kernel(const float* __restrict__ x, const float* __
     }
 }
 
+// x4 in both directions (the DeepLabV3+ decoder's up-sampling of the ASPP output): a thread owns one INPUT pixel's 4 x 4 block of
+// outputs and one 4-channel vector.  Those sixteen outputs interpolate between the 3 x 3 inputs around it, which the thread loads
+// (and activates) once -- 9 loads per 16 outputs where the kernel above does 64 -- and every output is formed by the same
+// expression from the same operands: bit-identical.
+__global__ void __launch_bounds__(256) bilinear_fwd_x4_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             int act, int ldx, float* __restrict__ out, int ldo, int n, int h, int w, int cv) {
+    const long long total = (long long)n * h * w * cv;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c0 = (int)(i % cv) * 4;
+    long long r = i / cv;
+    const int bx = (int)(r % w); r /= w;
+    const int by = (int)(r % h);
+    const long long img = r / h;
+    const bool aff = scale != nullptr;
+    float4 s = f4(0.f), t = f4(0.f);
+    if (aff) { s = ld4(scale + c0); t = ld4(shift + c0); }
+    const float* base = x + img * h * w * ldx + c0;
+    float4 v[3][3];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        int yy = by - 1 + dy;
+        yy = yy < 0 ? 0 : (yy > h - 1 ? h - 1 : yy);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            int xx = bx - 1 + dx;
+            xx = xx < 0 ? 0 : (xx > w - 1 ? w - 1 : xx);
+            v[dy][dx] = view_apply4(ld4(base + ((long long)yy * w + xx) * ldx), s, t, aff, act);
+        }
+    }
+    const int ho = h * 4, wo = w * 4;
+    Lerp lx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) lx[j] = lerp_of(bx * 4 + j, w, 0.25f);
+#pragma unroll
+    for (int jy = 0; jy < 4; ++jy) {
+        const int oy = by * 4 + jy;
+        const Lerp ly = lerp_of(oy, h, 0.25f);
+        // rows i0, i1 of the source are rows (i - (by - 1)) of the cache; a clamped border row was loaded under its clamped index
+        const int r0 = ly.i0 - (by - 1), r1 = ly.i1 - (by - 1);
+#pragma unroll
+        for (int jx = 0; jx < 4; ++jx) {
+            const int q0 = lx[jx].i0 - (bx - 1), q1 = lx[jx].i1 - (bx - 1);
+            float4 v00, v01, v10, v11;
+            // (compile-time indexed selects: the cache stays in registers)
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    if (a == r0 && b == q0) v00 = v[a][b];
+                    if (a == r0 && b == q1) v01 = v[a][b];
+                    if (a == r1 && b == q0) v10 = v[a][b];
+                    if (a == r1 && b == q1) v11 = v[a][b];
+                }
+            const float fx = lx[jx].f, fy = ly.f;
+            float4 top, bot, o;
+            top.x = v00.x + (v01.x - v00.x) * fx; top.y = v00.y + (v01.y - v00.y) * fx; top.z = v00.z + (v01.z - v00.z) * fx; top.w = v00.w + (v01.w - v00.w) * fx;
+            bot.x = v10.x + (v11.x - v10.x) * fx; bot.y = v10.y + (v11.y - v10.y) * fx; bot.z = v10.z + (v11.z - v10.z) * fx; bot.w = v10.w + (v11.w - v10.w) * fx;
+            o.x = top.x + (bot.x - top.x) * fy; o.y = top.y + (bot.y - top.y) * fy; o.z = top.z + (bot.z - top.z) * fy; o.w = top.w + (bot.w - top.w) * fy;
+            st4(out + ((img * ho + oy) * wo + bx * 4 + jx) * ldo + c0, o);
+        }
+    }
+}
+
 // gather form of the transposed resize: each input pixel sums the outputs that referenced it (deterministic)
 __global__ void bilinear_bwd_kernel(const float* __restrict__ g, int ldg, float* __restrict__ dx, int ldx, int n, int h, int w, int cv,
                                     int fy, int fx, int accumulate) {
@@ -542,6 +606,14 @@ int ssdseg_bilinear_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, float* 
     SSDSEG_ARG(c > 0 && c % 4 == 0, 9);
     SSDSEG_ARG(fy >= 1 && fx >= 1, 10);
     const long long total = (long long)n * h * fy * wdt * fx * (c / 4);
+    const char* bl = getenv("SSDSEG_BILINEAR");       // "gather": the general kernels (A/B runs, parity tests)
+    if (fy == 4 && fx == 4 && !(bl != nullptr && !strcmp(bl, "gather"))) {
+        const long long threads = (long long)n * h * wdt * (c / 4);
+        SSDSEG_LAUNCH(ctx, 4.0 * ((double)n * h * wdt * c + 4.0 * total), 0.0, bilinear_fwd_x4_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, in->x,
+                      in->scale, in->shift, in->act, ldx, out, ldo, n, h, wdt, c / 4);
+        SSDSEG_LAUNCH_CHECK();
+        return 0;
+    }
     SSDSEG_LAUNCH(ctx, 4.0 * ((double)n * h * wdt * c + 4.0 * total), 0.0, bilinear_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, in->x,
                   in->scale, in->shift, in->act, ldx, out, ldo, n, h, wdt, c / 4, fy, fx);
     SSDSEG_LAUNCH_CHECK();

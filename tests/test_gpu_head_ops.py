@@ -129,9 +129,19 @@ def test_gap(ctx, rng):
     assert rel_err(dx.download(), O.gap_bwd(g, h, w)) < 1e-6
 
 
-@pytest.mark.parametrize("n,h,w,c,fy,fx", [(2, 6, 8, 16, 4, 4), (2, 1, 1, 256, 30, 40), (1, 5, 7, 8, 2, 8), (1, 3, 3, 4, 1, 1)])
-def test_bilinear(ctx, rng, n, h, w, c, fy, fx):
+@pytest.mark.parametrize("n,h,w,c,fy,fx", [(2, 6, 8, 16, 4, 4), (2, 1, 1, 256, 30, 40), (1, 5, 7, 8, 2, 8), (1, 3, 3, 4, 1, 1), (3, 2, 1, 72, 4, 4)])
+def test_bilinear(ctx, rng, monkeypatch, n, h, w, c, fy, fx):
     from ssdseglib import _hip as H
+    if fy == 4 and fx == 4:
+        # the x4 forward kernel (one input pixel's 4x4 outputs per thread, 3x3 inputs loaded once) == the general gather kernel, bit for bit
+        xx, s1, s2, _ = view_inputs(rng, (n, h, w, c), O.ACT_RELU6)
+        bufs = [ctx.array(v) for v in (xx, s1, s2)]
+        o4, og = ctx.empty((n, h * 4, w * 4, c)), ctx.empty((n, h * 4, w * 4, c))
+        ctx.call("ssdseg_bilinear_fwd", H.view(*bufs, O.ACT_RELU6), c, o4, c, n, h, w, c, 4, 4)
+        monkeypatch.setenv("SSDSEG_BILINEAR", "gather")
+        ctx.call("ssdseg_bilinear_fwd", H.view(*bufs, O.ACT_RELU6), c, og, c, n, h, w, c, 4, 4)
+        monkeypatch.delenv("SSDSEG_BILINEAR")
+        np.testing.assert_array_equal(o4.download(), og.download())
     x, sc, sh, a = view_inputs(rng, (n, h, w, c), O.ACT_RELU6)
     ref = O.bilinear_fwd(a, fy, fx)
     ldo = c + 8                                     # write into a slice of a wider (concat) buffer
