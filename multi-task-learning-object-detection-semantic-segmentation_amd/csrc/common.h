@@ -131,21 +131,28 @@ __device__ __forceinline__ float4 view_apply4(float4 x, float4 s, float4 t, bool
 
 // same with the affine always applied (callers substitute scale = 1, shift = 0 for identity views at set-up time, so the
 // per-element path has no branch at all)
+// (two packed fmas + four v_med3 = 6 vector instructions; as fminf(fmaxf(fmaf())) per component the compiler emits 12 -- and in
+// the MFMA kernels every vector instruction of the staging path takes an issue slot from the matrix pipe.  med3(v, lo, hi) is
+// the clamp for lo <= hi; built with -ffp-contract=fast, s * x + t on the 2-vectors IS the fused multiply-add)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float4 view_affine4(float4 x, float4 s, float4 t, float lo, float hi) {
-    x.x = fminf(fmaxf(fmaf(s.x, x.x, t.x), lo), hi); x.y = fminf(fmaxf(fmaf(s.y, x.y, t.y), lo), hi);
-    x.z = fminf(fmaxf(fmaf(s.z, x.z, t.z), lo), hi); x.w = fminf(fmaxf(fmaf(s.w, x.w, t.w), lo), hi);
-    return x;
+    const f32x2 a = f32x2{s.x, s.y} * f32x2{x.x, x.y} + f32x2{t.x, t.y};
+    const f32x2 b = f32x2{s.z, s.w} * f32x2{x.z, x.w} + f32x2{t.z, t.w};
+    return make_float4(__builtin_amdgcn_fmed3f(a.x, lo, hi), __builtin_amdgcn_fmed3f(a.y, lo, hi), __builtin_amdgcn_fmed3f(b.x, lo, hi),
+                       __builtin_amdgcn_fmed3f(b.y, lo, hi));
 }
 
 // dy = s*mask(s*y+t)*g + k1*y + k0 on a 4-channel vector.  Identity gradient views are expressed as s = 1, t = k1 = k0 = 0,
 // act = NONE and y aliased to g (mask == 1 for finite values), so there is no per-element branch either.
+// (packed: z = s*y + t, base = k1*y + k0 and the final fma are three pairs of v_pk_fma; the mask selects s or 0 per component)
 __device__ __forceinline__ float4 gview_apply4(float4 g, float4 y, float4 s, float4 t, float4 k1, float4 k0, int act) {
-    float4 r;
-    r.x = fmaf(s.x * act_mask(fmaf(s.x, y.x, t.x), act), g.x, fmaf(k1.x, y.x, k0.x));
-    r.y = fmaf(s.y * act_mask(fmaf(s.y, y.y, t.y), act), g.y, fmaf(k1.y, y.y, k0.y));
-    r.z = fmaf(s.z * act_mask(fmaf(s.z, y.z, t.z), act), g.z, fmaf(k1.z, y.z, k0.z));
-    r.w = fmaf(s.w * act_mask(fmaf(s.w, y.w, t.w), act), g.w, fmaf(k1.w, y.w, k0.w));
-    return r;
+    const float lo = act_lo(act), hi = act_hi(act);
+    const f32x2 z0 = f32x2{s.x, s.y} * f32x2{y.x, y.y} + f32x2{t.x, t.y}, z1 = f32x2{s.z, s.w} * f32x2{y.z, y.w} + f32x2{t.z, t.w};
+    const f32x2 b0 = f32x2{k1.x, k1.y} * f32x2{y.x, y.y} + f32x2{k0.x, k0.y}, b1 = f32x2{k1.z, k1.w} * f32x2{y.z, y.w} + f32x2{k0.z, k0.w};
+    const f32x2 m0 = f32x2{(z0.x > lo && z0.x < hi) ? s.x : 0.f, (z0.y > lo && z0.y < hi) ? s.y : 0.f};
+    const f32x2 m1 = f32x2{(z1.x > lo && z1.x < hi) ? s.z : 0.f, (z1.y > lo && z1.y < hi) ? s.w : 0.f};
+    const f32x2 r0 = m0 * f32x2{g.x, g.y} + b0, r1 = m1 * f32x2{g.z, g.w} + b1;
+    return make_float4(r0.x, r0.y, r1.x, r1.y);
 }
 
 // XCD-aware block -> work mapping.  Workgroups are handed to the 8 XCDs round-robin in launch order and every XCD has its
