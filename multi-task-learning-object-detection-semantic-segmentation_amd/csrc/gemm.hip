@@ -1241,14 +1241,27 @@ int pw_wgrad_try(ssdseg_ctx* ctx, const WGradArgs& w, float* dw) {
     a.M = w.M; a.K = w.K; a.N = w.N;
     a.x_bytes = (unsigned)((((long long)w.M - 1) * w.ldx + w.K) * 4);
     a.g_bytes = (unsigned)((((long long)w.M - 1) * w.ldy + w.N) * 4);
-    const int k = w.K, n = w.N;
-    // tile = (32 JX WK) x (32 JY WN): the smallest one that covers the layer's channels, else the 256 x 128 / 128 x 256 block tiles
-    int rc;
-    if (k <= 32) rc = n <= 32 ? pw_wgrad_launch<1, 1, 1, 1>(ctx, a, dw) : (n <= 64 ? pw_wgrad_launch<1, 2, 1, 1>(ctx, a, dw) : pw_wgrad_launch<1, 4, 1, 1>(ctx, a, dw));
-    else if (k <= 64) rc = n <= 32 ? pw_wgrad_launch<2, 1, 1, 1>(ctx, a, dw) : (n <= 64 ? pw_wgrad_launch<2, 2, 1, 1>(ctx, a, dw) : pw_wgrad_launch<2, 2, 1, 2>(ctx, a, dw));
-    else if (k <= 128) rc = n <= 32 ? pw_wgrad_launch<4, 1, 1, 1>(ctx, a, dw) : (n <= 64 ? pw_wgrad_launch<2, 2, 2, 1>(ctx, a, dw) : (n <= 128 ? pw_wgrad_launch<2, 2, 2, 2>(ctx, a, dw) : pw_wgrad_launch<2, 2, 2, 4>(ctx, a, dw)));
-    else rc = n <= 32 ? pw_wgrad_launch<4, 1, 2, 1>(ctx, a, dw) : (n <= 64 ? pw_wgrad_launch<2, 2, 4, 1>(ctx, a, dw) : pw_wgrad_launch<2, 2, 4, 2>(ctx, a, dw));
-    return rc;
+    // tile = (32 JX WK) x (32 JY WN), chosen per layer among the instantiated shapes (K = 160 on a 256-row tile wastes 37 % of the
+    // MFMAs, three 64-row tiles 17 %; a 24 -> 144 layer on 64-column tiles reads x three times)
+    struct Shape { int kt, nt; int (*launch)(ssdseg_ctx*, PwWgArgs, float*); };
+    static const Shape shapes[] = {
+        {256, 128, &pw_wgrad_launch<2, 2, 4, 2>}, {128, 256, &pw_wgrad_launch<2, 2, 2, 4>}, {128, 128, &pw_wgrad_launch<2, 2, 2, 2>},
+        {256, 64, &pw_wgrad_launch<2, 2, 4, 1>},  {64, 128, &pw_wgrad_launch<2, 2, 1, 2>},  {128, 64, &pw_wgrad_launch<2, 2, 2, 1>},
+        {256, 32, &pw_wgrad_launch<4, 1, 2, 1>},  {64, 64, &pw_wgrad_launch<2, 2, 1, 1>},   {32, 128, &pw_wgrad_launch<1, 4, 1, 1>},
+        {128, 32, &pw_wgrad_launch<4, 1, 1, 1>},  {32, 64, &pw_wgrad_launch<1, 2, 1, 1>},   {64, 32, &pw_wgrad_launch<2, 1, 1, 1>},
+        {32, 32, &pw_wgrad_launch<1, 1, 1, 1>}};
+    // estimated time of a shape = max(padded MFMA work at ~110 TFLOP/s, operand traffic at ~4.5 TB/s): every n-tile re-reads the x
+    // columns of its k-tile and vice versa, so small tiles cost traffic and large ones padding
+    const Shape* best = nullptr;
+    double best_t = 0.0;
+    for (const Shape& sh : shapes) {
+        const double tk = cdiv(w.K, sh.kt), tn = cdiv(w.N, sh.nt);
+        const double t_mfma = 2.0 * w.M * (tk * sh.kt) * (tn * sh.nt) / 110e12;
+        const double t_hbm = 4.0 * w.M * ((double)w.K * tn + (double)w.N * tk) / 4.5e12;
+        const double t = t_mfma > t_hbm ? t_mfma : t_hbm;
+        if (best == nullptr || t < best_t * 0.999) { best = &sh; best_t = t; }      // (listed largest first: ties keep the larger tile)
+    }
+    return best->launch(ctx, a, dw);
 }
 
 // picks the tile shape / split count for dw[k][n] = sum_m x[m][k]*dy[m][n], launches, reduces the split partials
