@@ -889,7 +889,8 @@ int pw_tile_launch(ssdseg_ctx* ctx, PwTArgs a, int nparts_y, double view_bytes) 
     const int ntiles = a.nout <= 160 ? 1 : cdiv(a.nout, 256);
     a.ncols = (cdiv(a.nout, ntiles) + 3) / 4 * 4;
     int wn = cdiv(a.ncols, 32);
-    const bool big = a.M >= 65536;                       // >= 256 row tiles of 256 rows: eight-wave blocks, one per CU
+    const char* bige = getenv("SSDSEG_PW_TILE_BIG_ROWS");      // (A/B runs) rows from which the eight-wave 256-row blocks are used
+    const bool big = a.M >= (bige != nullptr ? atoll(bige) : 65536);                       // >= 256 row tiles of 256 rows: eight-wave blocks, one per CU
     // column tiles of <= 160: four-wave blocks (two blocks per CU), and the input-gradient kernel whatever its size (its gradient
     // view staging and epilogue need ~60 registers more: 6- and 8-tile instantiations spill)
     if ((!big || MODE == 1) && wn > 5) {
