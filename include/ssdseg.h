@@ -196,6 +196,17 @@ int ssdseg_dwconv_bwd_bn(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w,
 int ssdseg_pwconv_parts(int m, int n, int* nparts_host);
 int ssdseg_pwconv_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const float* w, float* y, int ldy, int m,
                       int k, int n, float* stats);
+/* The tile GEMM behind the forward streams the weights with the reduction channel contiguous (Wt[n][k]); ssdseg_pwconv_fwd
+ * makes that copy itself, one small launch per call.  A caller that owns all layers of a model (ssdseglib/_engine.py) does it
+ * ONCE per step for all of them instead: ssdseg_pwconv_wt_floats() tells whether the default dispatch of a shape uses such a
+ * copy (k*n floats, 0 = no), ssdseg_transpose_batch() fills the copies of a whole table of layers in one launch (table on the
+ * device: per matrix four 64-bit words {source pointer W[k][n], destination pointer Wt[n][k], k, n}; max_tiles = the largest
+ * ceil(k/32)*ceil(n/32) of the table; total_floats = sum of k*n, for the timing registry), and ssdseg_pwconv_fwd_wt() takes the
+ * copy (wt may be NULL = as ssdseg_pwconv_fwd; a copy passed for a shape that runs on another kernel family is ignored). */
+int ssdseg_pwconv_wt_floats(int m, int ldx, int k, int n, int* floats_host);
+int ssdseg_transpose_batch(ssdseg_ctx* ctx, const long long* table, int nmat, int max_tiles, long long total_floats);
+int ssdseg_pwconv_fwd_wt(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const float* w, const float* wt, float* y, int ldy,
+                         int m, int k, int n, float* stats);
 /* dx[m][k] = dy[m][n] * w^T; residual != NULL: dx += residual (Add backward, models.py:162);
  * accumulate != 0: dx += previous contents. */
 int ssdseg_pwconv_bwd_data(ssdseg_ctx* ctx, const ssdseg_gview* dy, int ldy, const float* w, float* dx, int ldx,

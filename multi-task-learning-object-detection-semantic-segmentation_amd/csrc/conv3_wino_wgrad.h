@@ -40,13 +40,22 @@ constexpr int WWG_THREADS = 512;
 struct WinoWgArgs {
     const float* xp;     // [n][h+2][w+2][cin]  activated input with a zero border
     const float* dy;     // [n][h][w][cout]
-    float* part;         // [splits][16][cin][cout]
+    float* part;         // [patch][slots][16][64][64]: partial dU per (patch, range of steps)
     int n, h, w, cin, cout;
     int cpatches, npatches;
     int strips;          // w / 32
-    int steps, steps_per_split;     // steps = n * (h / 2) * strips
+    int steps;           // n * (h / 2) * strips
+    // Even split of patches x steps over the CUs (one 100 KB block per CU): blocks 0 .. full * patches - 1 take `span` steps of one
+    // patch each (chunk-major: the blocks of a chunk read the same pixels); the remaining `tail` = steps - full * span steps of all
+    // patches form one patch-major sequence of patches * tail units cut into pieces of `span` units -- a tail block works on up to
+    // three patches in turn.  The decoder conv: 20 patches x 9600 steps on 256 CUs = 750 units per block (12 full chunks = 240
+    // blocks + 16 tail blocks) instead of 240 blocks of 800 steps and 16 idle CUs.
+    int span, full, tail, slots;
     unsigned xp_bytes, dy_bytes, part_bytes;
 };
+
+// slot of the partial a tail block `tb` writes for patch `patch` (the finalize kernel walks the same numbering)
+__device__ __forceinline__ int wwg_tail_first_block(int patch, int tail, int span) { return (int)(((long long)patch * tail) / span); }
 
 typedef float wwg_f2 __attribute__((ext_vector_type(2)));
 typedef unsigned wwg_u2 __attribute__((ext_vector_type(2)));
@@ -60,11 +69,27 @@ __global__ void __launch_bounds__(WWG_THREADS, 2) conv3_wino_wgrad_kernel(WinoWg
     const int a = wave_u >> 1, bh = wave_u & 1;
     const unsigned L = xcd_logical_id(blockIdx.x, gridDim.x);
     const int patches = p.cpatches * p.npatches;
-    const int patch = (int)(L % (unsigned)patches), split = (int)(L / (unsigned)patches);
+    const int nfull = p.full * patches;
+    const bool is_tail = (int)L >= nfull;
+    // units of this block: a full block owns steps [chunk * span, + span) of ONE patch; a tail block owns units [u, uend) of the
+    // patch-major tail sequence (unit = patch * tail + step - full * span)
+    int u = is_tail ? ((int)L - nfull) * p.span : 0;
+    const int uend = is_tail ? (u + p.span < patches * p.tail ? u + p.span : patches * p.tail) : p.span;
+    const pwt_i32x4 rx = pwt_make_rsrc(p.xp, p.xp_bytes);
+    const pwt_i32x4 ry = pwt_make_rsrc(p.dy, p.dy_bytes);
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(p.part, 0, p.part_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const int wp = p.w + 2;
+
+  // one pass = one (patch, step range): accumulators are zeroed at its top and stored at its bottom, nothing but `u` lives across
+  while (u < uend) {
+    const int patch = is_tail ? u / p.tail : (int)(L % (unsigned)patches);
+    const int s0 = is_tail ? p.full * p.span + (u - patch * p.tail) : (int)(L / (unsigned)patches) * p.span;
+    const int seg = is_tail ? (uend - u < p.tail - (u - patch * p.tail) ? uend - u : p.tail - (u - patch * p.tail)) : p.span;
+    const int s1 = s0 + seg;
+    const int slot = is_tail ? p.full + ((int)L - nfull) - wwg_tail_first_block(patch, p.tail, p.span) : (int)(L / (unsigned)patches);
+    u += seg;
     const int c0 = (patch / p.npatches) * WWG_KT, n0 = (patch % p.npatches) * WWG_NT;
-    const int s0 = split * p.steps_per_split;
-    int s1 = s0 + p.steps_per_split;
-    if (s1 > p.steps) s1 = p.steps;
 
     f32x16 acc[2][2][2];      // [position of the half][j: input channel of the pair][j': output channel of the pair]
 #pragma unroll
@@ -77,10 +102,6 @@ __global__ void __launch_bounds__(WWG_THREADS, 2) conv3_wino_wgrad_kernel(WinoWg
                 for (int e = 0; e < 16; ++e) acc[b][j][jj][e] = 0.f;
 
     // ---- DMA slots.  Input patch: 136 pixels x 16 quads = 34 wave-instructions (wave w issues w, w+8, ...); dY: 64 x 16 = 16.
-    const pwt_i32x4 rx = pwt_make_rsrc(p.xp, p.xp_bytes);
-    const pwt_i32x4 ry = pwt_make_rsrc(p.dy, p.dy_bytes);
-    constexpr unsigned OOB = 0x80000000u;
-    const int wp = p.w + 2;
     unsigned xgo[5], ygo[2];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
@@ -196,47 +217,54 @@ __global__ void __launch_bounds__(WWG_THREADS, 2) conv3_wino_wgrad_kernel(WinoWg
         WWG_ISSUE(cur);                                          // step s+2
         cur ^= 1;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // nothing in flight into LDS when the block ends
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // nothing in flight into LDS when the pass ends (a wave only ever
+                                                               // writes its own LDS slots, and everybody is past the last barrier)
 #undef WWG_ISSUE
 
-    // ---- partial dU of this split.  C/D layout: column = lane & 31 (pair r' of output channels), row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
-    // (pair r of input channels): element (c0 + 2 row + j, n0 + 2 col + j'); the two j' of a lane are adjacent in memory.
-    // Buffer stores: one 32-bit lane offset, the (e, j) part of the address in the scalar offset, rows beyond cin dropped by the
-    // range check (64-bit pointers for 64 stores would not fit beside the accumulators).
-    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(p.part, 0, p.part_bytes, 0x00020000);
+    // ---- partial dU of this pass.  C/D layout: column = lane & 31 (pair r' of output channels), row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+    // (pair r of input channels): patch element (2 row + j, 2 col + j'); the two j' of a lane are adjacent in memory.  Compact
+    // [64][64] patches (rows beyond cin / columns beyond cout hold products of zeros and are never read).
+    // Buffer stores: one 32-bit lane offset, the (e, j) part of the address in the scalar offset (64-bit pointers for 64 stores
+    // would not fit beside the accumulators).
     const int col = lane & 31, hh = lane >> 5;
-    const int nn = n0 + 2 * col;
-    const unsigned lane_off = (unsigned)(((long long)(c0 + 8 * hh) * p.cout + nn) * 4);
-    const int crow = c0 + 8 * hh;       // + 2 * ((e & 3) + 8 * (e >> 2)) + j
+    const unsigned lane_off = (unsigned)(((8 * hh) * WWG_NT + 2 * col) * 4);
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int k = 4 * a + 2 * bh + b;
-        const int kbase = (int)((((long long)split * 16 + k) * p.cin) * p.cout * 4);
+        const int kbase = (int)(((((long long)patch * p.slots + slot) * 16 + k) * WWG_KT) * WWG_NT * 4);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int dr = 2 * ((e & 3) + 8 * (e >> 2)) + j;
-                const bool ok = crow + dr < p.cin && nn < p.cout;       // cout is a multiple of 4, nn even: nn + 1 is in range with nn
                 const float lo = acc[b][j][0][e], hi2 = acc[b][j][1][e];
                 wwg_f2 v;
                 v.x = lo; v.y = hi2;
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wwg_u2, v), rp, ok ? lane_off : 0x80000000u, kbase + dr * p.cout * 4, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(wwg_u2, v), rp, lane_off, kbase + dr * WWG_NT * 4, 0);
             }
     }
+  }   // next (patch, step range) of a tail block
 }
 
-// dw[i][j][c][n] = sum_ab G[a][i] G[b][j] s(a) s(b) sum_split part[split][4a+b][c][n],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],
-// s(3) = -1 (the signs of A's last row / column the main kernel left out), s = +1 otherwise.  Splits are summed in index order.
-__global__ void __launch_bounds__(256) conv3_wino_wgrad_finalize_kernel(const float* __restrict__ part, float* __restrict__ dw, int splits, int cin, int cout) {
+// dw[i][j][c][n] = sum_ab G[a][i] G[b][j] s(a) s(b) sum_slot part[patch][slot][4a+b][c % 64][n % 64],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],
+// s(3) = -1 (the signs of A's last row / column the main kernel left out), s = +1 otherwise.  Slots are summed in index order:
+// the `full` chunk partials, then the tail pieces of this patch.
+__global__ void __launch_bounds__(256) conv3_wino_wgrad_finalize_kernel(const float* __restrict__ part, float* __restrict__ dw, int cin, int cout, int npatches,
+                                                                        int full, int tail, int span, int slots) {
     const long long cn = (long long)cin * cout;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= cn) return;
+    const int c = (int)(i / cout), n = (int)(i - (long long)c * cout);
+    const int patch = (c / WWG_KT) * npatches + n / WWG_NT;
+    const int local = (c % WWG_KT) * WWG_NT + n % WWG_NT;
+    int nslots = full;
+    if (tail > 0) nslots += (int)((((long long)patch + 1) * tail - 1) / span) - wwg_tail_first_block(patch, tail, span) + 1;
+    const float* base = part + (long long)patch * slots * 16 * (WWG_KT * WWG_NT) + local;
     float u[4][4];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         float s = 0.f;
-        for (int sp = 0; sp < splits; ++sp) s += part[((long long)sp * 16 + k) * cn + i];
+        for (int sp = 0; sp < nslots; ++sp) s += base[((long long)sp * 16 + k) * (WWG_KT * WWG_NT)];
         u[k >> 2][k & 3] = ((k >> 2) == 3) != ((k & 3) == 3) ? -s : s;
     }
     float tmp[3][4];      // G^T u

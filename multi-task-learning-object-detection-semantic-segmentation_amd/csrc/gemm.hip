@@ -873,8 +873,13 @@ int pwt_launch_inst(ssdseg_ctx* ctx, const PwTArgs& a, dim3 grid, double cost_by
 // epilogue loses there) with a reduction of <= 384 channels and a wide side (>= 256) somewhere: decoder sepconv 0.76, encoder
 // output conv 0.80, expand convs of blocks 7-10 0.84-0.93, ASPP atrous branches 0.93-0.98; long reductions onto few columns
 // (expand convs of blocks 11-16: one column tile, 75-300 blocks) lose 1.1-1.4x.
+// Round 2, second table (profiles/r02_pw_tile_short_m_per_layer.txt): with 64- / 32-column tiles the tile kernel also wins every
+// FORWARD below 65,536 rows (project convs of the 30x40 / 15x20 stages 0.8, the SSD head and extra-feature-map convs 0.45-0.8) and the
+// plain input gradients of <= 16k rows (expand convs of blocks 14-16: 0.75-0.85, extra feature maps 0.45).
 bool pw_tile_default(int mode, long long rows, int cred, int nout, bool fused_bn, bool accumulate) {
-    if (mode == 0) return nout >= 256 || (rows >= 500000 && cred >= 256);
+    const bool pinned = getenv("SSDSEG_PWT_SMALL") != nullptr && getenv("SSDSEG_PWT_SMALL")[0] == '0';
+    if (mode == 0) return nout >= 256 || (rows >= 500000 && cred >= 256) || (rows < 65536 && !pinned);
+    if (!fused_bn && !accumulate && rows <= 16384 && !pinned) return true;
     return !fused_bn && !accumulate && cred <= 384 && (nout >= 256 || cred >= 256);
 }
 
@@ -883,10 +888,34 @@ bool pw_tile_takes(long long rows, int lda, int cred, int nout) {
     return cred % 8 == 0 && cred >= 64 && nout % 4 == 0 && rows * (long long)lda * 4 < (1LL << 31) && (long long)nout * cred * 4 < (1LL << 31);
 }
 
+// Short-M layers (the 30x40 / 15x20 stages and the extra feature maps: 38,400 / 9,600 / 2,560 ... rows at batch 32): 128-row tiles
+// give 300 / 75 / 20 row tiles for 256 CUs, so the column tile is what makes the blocks.  Measured per layer
+// (profiles/r02_pw_tile_short_m_per_layer.txt; blocks of one or two waves lost everywhere: every block stages its own weight
+// tile, and LDS then holds three waves per CU): 64-column tiles, 32 where 64 would pad more than a quarter, 32 for <= 16k rows.
+// SSDSEG_PWT_SMALL=<ncols> overrides the width for A/B runs, "0" restores one tile of <= 160 columns.
+constexpr int PWT_SHORT_ROWS = 65536;
+int pwt_short_ncols(int mode, long long rows, int cred, int nout) {
+    const char* e = getenv("SSDSEG_PWT_SMALL");
+    if (e != nullptr) return atoi(e) >= 32 ? atoi(e) : 0;
+    const int t64 = cdiv(nout, 64);
+    const bool pad64 = cdiv((cdiv(nout, t64) + 3) / 4 * 4, 32) * 32 * t64 * 4 > nout * 5;
+    if (mode == 0) {
+        if (rows <= 16384) return nout >= 512 ? 0 : 32;
+        if (cred <= 64) return 128;
+        return (nout <= 64 || pad64) ? 32 : 64;
+    }
+    if (rows <= 16384) return 32;
+    return nout <= 64 ? 64 : (pad64 ? 32 : 64);
+}
+
 // nparts_y: number of blocks along y == number of partial rows the caller sized its statistics table for (0: free choice)
 template <int MODE>
 int pw_tile_launch(ssdseg_ctx* ctx, PwTArgs a, int nparts_y, double view_bytes) {
-    const int ntiles = a.nout <= 160 ? 1 : cdiv(a.nout, 256);
+    int ntiles = a.nout <= 160 ? 1 : cdiv(a.nout, 256);
+    if (a.M < PWT_SHORT_ROWS) {
+        const int nc = pwt_short_ncols(MODE, a.M, a.cred, a.nout);
+        if (nc > 0) ntiles = cdiv(a.nout, nc);
+    }
     a.ncols = (cdiv(a.nout, ntiles) + 3) / 4 * 4;
     int wn = cdiv(a.ncols, 32);
     const char* bige = getenv("SSDSEG_PW_TILE_BIG_ROWS");      // (A/B runs) rows from which the eight-wave 256-row blocks are used
@@ -919,7 +948,9 @@ int pw_tile_launch(ssdseg_ctx* ctx, PwTArgs a, int nparts_y, double view_bytes) 
             PWT_CASE(8, 8);
         }
     }
+    if (wn <= 1) PWT_CASE(4, 1);
     if (wn <= 2) PWT_CASE(4, 2);
+    if (wn <= 3) PWT_CASE(4, 3);
     if (wn <= 4) PWT_CASE(4, 4);
     PWT_CASE(4, 5);
 #undef PWT_CASE
@@ -1002,19 +1033,22 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
 // SSDSEG_SPLITK=1 enables it (read per call; the parity tests run that family too).
 bool splitk_enabled() { return getenv("SSDSEG_SPLITK") != nullptr && getenv("SSDSEG_SPLITK")[0] == '1'; }
 
+// wt_pre (forward only, may be nullptr): the weights already transposed to [J][R] by ssdseg_transpose_batch
 template <int MODE, int LD>
-int launch_rowA(ssdseg_ctx* ctx, const RowAArgs& a0) {
+int launch_rowA(ssdseg_ctx* ctx, const RowAArgs& a0, const float* wt_pre = nullptr) {
     RowAArgs a = a0;
     int wn = rowA_wn(a.I, a.J);
     const int nparts = rowA_grid_y(a.I, a.J);   // BN-statistics partial rows the caller allocated: fixed by (I, J) alone
-    if (LD == 0 && pw_tile_mode() != 0 && pw_tile_takes(a.I, a.lda, a.R, a.J) && (pw_tile_mode() == 1 || pw_tile_default(MODE, a.I, a.R, a.J, false, a.accumulate != 0 || a.residual != nullptr))) {
+    if (LD == 0 && pw_tile_mode() != 0 && pw_tile_takes(a.I, a.lda, a.R, a.J) && !(MODE == 0 && (a.residual != nullptr || a.accumulate != 0)) && (pw_tile_mode() == 1 || pw_tile_default(MODE, a.I, a.R, a.J, false, a.accumulate != 0 || a.residual != nullptr))) {
         PwTArgs t{};
         t.a0 = a.a0; t.a1 = (MODE == 1 && a.cs != nullptr) ? a.a1 : a.a0;
         t.cs = a.cs; t.ct = a.ct; t.ck1 = a.ck1; t.ck0 = a.ck0; t.act = a.act; t.lda = a.lda;
         t.out = a.out; t.ldo = a.ldo; t.residual = a.residual; t.ldr = a.ldr; t.accumulate = a.accumulate;
         t.stats = a.stats; t.M = a.I; t.cred = a.R; t.nout = a.J;
         t.wt = a.b;
-        if (MODE == 0) {
+        if (MODE == 0 && wt_pre != nullptr) {
+            t.wt = wt_pre;
+        } else if (MODE == 0) {
             // the reduction channel must be contiguous in the staged weight rows: W[k][n] -> Wt[n][k] (one small transpose per call)
             void* ws;
             int rc = ssdseg_workspace(ctx, (size_t)a.R * a.J * sizeof(float), &ws);
@@ -1541,13 +1575,17 @@ int conv3_wino_wgrad_launch(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, con
     a.strips = w / 32;
     a.steps = n * (h / 2) * a.strips;
     const int patches = a.cpatches * a.npatches;
-    int splits = ctx->num_cus / patches;                    // one block per CU (100 KB of LDS, 8 waves)
-    if (splits > a.steps / 4) splits = a.steps / 4;
-    if (splits < 1) splits = 1;
-    a.steps_per_split = (a.steps + splits - 1) / splits;
-    splits = (a.steps + a.steps_per_split - 1) / a.steps_per_split;
+    // one block per CU (100 KB of LDS, 8 waves): patches x steps units dealt evenly (WinoWgArgs); >= 4 steps per block
+    long long span = ((long long)patches * a.steps + ctx->num_cus - 1) / ctx->num_cus;
+    if (span < 4) span = 4;
+    if (span > a.steps) span = a.steps;
+    a.span = (int)span;
+    a.full = a.steps / a.span;
+    a.tail = a.steps - a.full * a.span;
+    a.slots = a.full + (a.tail > 0 ? (a.tail + a.span - 1) / a.span + 1 : 0);
+    const int nblocks = a.full * patches + (int)(((long long)patches * a.tail + a.span - 1) / a.span);
     const size_t xpb = xsaved != nullptr ? 0 : align256((size_t)n * (h + 2) * (w + 2) * cin * sizeof(float));
-    const size_t pb = (size_t)splits * 16 * cin * cout * sizeof(float);
+    const size_t pb = (size_t)patches * a.slots * 16 * WWG_KT * WWG_NT * sizeof(float);
     SSDSEG_ARG(pb < ((size_t)1 << 31), 9);
     void* ws;
     int rc = ssdseg_workspace(ctx, xpb + pb, &ws);
@@ -1571,13 +1609,38 @@ int conv3_wino_wgrad_launch(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, con
     }
     const double cost_bytes = 4.0 * (m * cin + m * cout + 9.0 * cin * cout);   // X + dY + dW
     const double cost_flops = 8.0 * m * cin * cout;                             // executed MFMA flops: 16/36 of the direct form's 18 m cin cout
-    SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, conv3_wino_wgrad_kernel, dim3((unsigned)(patches * splits)), dim3(WWG_THREADS), WWG_LDS_BYTES, a);
+    SSDSEG_LAUNCH(ctx, cost_bytes, cost_flops, conv3_wino_wgrad_kernel, dim3((unsigned)nblocks), dim3(WWG_THREADS), WWG_LDS_BYTES, a);
     SSDSEG_LAUNCH_CHECK();
     const long long cn = (long long)cin * cout;
-    SSDSEG_LAUNCH(ctx, 4.0 * cn * (16.0 * splits + 9.0), 0.0, conv3_wino_wgrad_finalize_kernel, dim3((unsigned)((cn + 255) / 256)), dim3(256), 0, (const float*)a.part, dw,
-                  splits, cin, cout);
+    SSDSEG_LAUNCH(ctx, 4.0 * cn * (16.0 * a.slots + 9.0), 0.0, conv3_wino_wgrad_finalize_kernel, dim3((unsigned)((cn + 255) / 256)), dim3(256), 0, (const float*)a.part, dw,
+                  cin, cout, a.npatches, a.full, a.tail, a.span, a.slots);
     SSDSEG_LAUNCH_CHECK();
     return 0;
+}
+
+// Wt[n][k] = W[k][n] for a whole table of matrices in ONE launch: blockIdx.y = matrix, blockIdx.x strides over its 32x32 tiles.
+// table[mat] = {source pointer, destination pointer, k, n} as four 64-bit words.
+__global__ void __launch_bounds__(256) transpose_batch_kernel(const long long* __restrict__ table) {
+    __shared__ float tile[32][33];
+    const long long* e = table + 4 * (long long)blockIdx.y;
+    const float* __restrict__ w = reinterpret_cast<const float*>(e[0]);
+    float* __restrict__ wt = reinterpret_cast<float*>(e[1]);
+    const int k = (int)e[2], n = (int)e[3];
+    const int tn = (n + 31) / 32, tk = (k + 31) / 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int t = blockIdx.x; t < tn * tk; t += gridDim.x) {
+        const int c0 = (t / tn) * 32, n0 = (t % tn) * 32;
+        for (int r = ty; r < 32; r += 8) {
+            const int c = c0 + r, j = n0 + tx;
+            tile[r][tx] = (c < k && j < n) ? w[(long long)c * n + j] : 0.f;
+        }
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {
+            const int j = n0 + r, c = c0 + tx;
+            if (j < n && c < k) wt[(long long)j * k + c] = tile[tx][r];
+        }
+        __syncthreads();
+    }
 }
 
 }  // namespace
@@ -1592,8 +1655,8 @@ int ssdseg_pwconv_parts(int m, int n, int* nparts_host) {
     return 0;
 }
 
-int ssdseg_pwconv_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const float* w, float* y, int ldy, int m, int k,
-                      int n, float* stats) {
+int ssdseg_pwconv_fwd_wt(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const float* w, const float* wt, float* y, int ldy, int m,
+                         int k, int n, float* stats) {
     SSDSEG_ARG(ctx != nullptr, 1);
     SSDSEG_ARG(in != nullptr && in->x != nullptr && ((in->scale == nullptr) == (in->shift == nullptr)), 2);
     SSDSEG_ARG(ldx >= k && ldx % 4 == 0, 3);
@@ -1609,7 +1672,32 @@ int ssdseg_pwconv_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const flo
     a.out = y; a.ldo = ldy;
     a.stats = stats;
     a.I = m; a.R = k; a.J = n;
-    return launch_rowA<0, 0>(ctx, a);
+    return launch_rowA<0, 0>(ctx, a, wt);
+}
+
+int ssdseg_pwconv_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const float* w, float* y, int ldy, int m, int k,
+                      int n, float* stats) {
+    return ssdseg_pwconv_fwd_wt(ctx, in, ldx, w, nullptr, y, ldy, m, k, n, stats);
+}
+
+int ssdseg_pwconv_wt_floats(int m, int ldx, int k, int n, int* floats_host) {
+    SSDSEG_ARG(m > 0, 1);
+    SSDSEG_ARG(k > 0 && n > 0, 3);
+    SSDSEG_ARG(floats_host != nullptr, 5);
+    const bool tile = pw_tile_mode() != 0 && pw_tile_takes(m, ldx, k, n) && (pw_tile_mode() == 1 || pw_tile_default(0, m, k, n, false, false));
+    *floats_host = tile ? k * n : 0;
+    return 0;
+}
+
+int ssdseg_transpose_batch(ssdseg_ctx* ctx, const long long* table, int nmat, int max_tiles, long long total_floats) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(table != nullptr, 2);
+    SSDSEG_ARG(nmat > 0, 3);
+    SSDSEG_ARG(max_tiles > 0, 4);
+    const int gx = max_tiles < 64 ? max_tiles : 64;
+    SSDSEG_LAUNCH(ctx, 8.0 * (double)total_floats, 0.0, transpose_batch_kernel, dim3(gx, nmat, 1), dim3(256), 0, table);
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
 }
 
 int ssdseg_pwconv_bwd_data(ssdseg_ctx* ctx, const ssdseg_gview* dy, int ldy, const float* w, float* dx, int ldx, int m,

@@ -245,12 +245,14 @@ class PwOp(Op):
             out.nparts = eng.ctx.parts("ssdseg_pwconv_parts", self.m, self.n)
             out.stats = eng.ctx.empty((out.nparts, 2, self.n))
         self.out_val: Optional[Val] = None
+        # the forward tile GEMM streams Wt[n][k]: one batched transposition per step for all layers (Engine._refresh_wt)
+        self.wt = eng.register_wt(self.w, self.m, inp.store.ld, self.k, self.n)
 
     fuse_input_bn = False   # set by the lowering when this conv is the only consumer of a (wide) BatchNorm(+ReLU) output
 
     def fwd(self):
-        self.e.ctx.call("ssdseg_pwconv_fwd", self.inp.view(), self.inp.store.ld, self.w, self.out.buf, self.out.ld, self.m, self.k, self.n,
-                        self.out.stats)
+        self.e.ctx.call("ssdseg_pwconv_fwd_wt", self.inp.view(), self.inp.store.ld, self.w, self.wt, self.out.buf, self.out.ld, self.m, self.k,
+                        self.n, self.out.stats)
 
     def bwd(self):
         s = self.inp.store
@@ -653,6 +655,8 @@ class Engine:
         self.stores: List[Store] = []
         self.output_vals: List[Val] = []
         self.loss_ops: Dict[str, Op] = {}
+        self._wt_rows: List[Tuple[int, int, int, int]] = []
+        self._wt_table = None
         self._alloc_params(grad_bucket)
         self._plan_concats()
         for layer in model.layers:
@@ -734,6 +738,24 @@ class Engine:
             reg[key] = dict(buf=self.ctx.zeros(phys), rows=rows, cols=dims[-1], lds=dims[-1], ldd=pdims[-1], layer=layer, wname=wname,
                             which=which)
         return reg[key]["buf"]
+
+    def register_wt(self, w: H.DeviceBuffer, m: int, ldx: int, k: int, n: int):
+        """device buffer for the transposed copy Wt[n][k] of a pointwise kernel, refreshed by `_refresh_wt` at the start of every
+        forward pass (None where the library's default dispatch for this shape does not stream a transposed copy)"""
+        if self.ctx.parts("ssdseg_pwconv_wt_floats", m, ldx, k, n) == 0:
+            return None
+        wt = self.ctx.empty((n, k))
+        self._wt_rows.append((w.ptr, wt.ptr, k, n))
+        self._wt_table = None
+        return wt
+
+    def _refresh_wt(self):
+        if not self._wt_rows:
+            return
+        if self._wt_table is None:
+            self._wt_table = self.ctx.array(np.asarray(self._wt_rows, dtype=np.int64))
+        tiles = max(-(-k // 32) * -(-n // 32) for _, _, k, n in self._wt_rows)
+        self.ctx.call("ssdseg_transpose_batch", self._wt_table, len(self._wt_rows), tiles, sum(k * n for _, _, k, n in self._wt_rows))
 
     def param_view(self, layer, wname):
         which, off, shape = self.P["index"][(id(layer), wname)]
@@ -1130,6 +1152,7 @@ class Engine:
 
     def forward(self):
         self._sync_padded("p", to_bucket=False)          # padded copies of the weights <- bucket (no-op for most models)
+        self._refresh_wt()                                # transposed copies of the pointwise kernels: one launch
         for op in self.ops:
             op.fwd()
         if self.training:

@@ -84,6 +84,9 @@ _SIGNATURES = {
     "ssdseg_dwconv_bwd_bn": [_vp, _VP, _vp, _GP, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "ssdseg_pwconv_parts": [_i, _i, _ip],
     "ssdseg_pwconv_fwd": [_vp, _VP, _i, _vp, _vp, _i, _i, _i, _i, _vp],
+    "ssdseg_pwconv_wt_floats": [_i, _i, _i, _i, _ip],
+    "ssdseg_transpose_batch": [_vp, _vp, _i, _i, C.c_longlong],
+    "ssdseg_pwconv_fwd_wt": [_vp, _VP, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ssdseg_pwconv_bwd_data": [_vp, _GP, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i],
     "ssdseg_pwconv_bwd_weight": [_vp, _VP, _i, _GP, _i, _vp, _i, _i, _i],
     "ssdseg_pwconv_bwd": [_vp, _VP, _i, _GP, _i, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i],

@@ -176,6 +176,16 @@ def test_pwconv_fwd_bwd(ctx, rng, kernel_family, m, k, n):
     st = stats.download().astype(np.float64).sum(axis=0)
     assert np.abs(st[0] - y_ref.sum(axis=0)).max() < 1e-4 * max(1.0, np.abs(y_ref).sum(axis=0).max())
     assert rel_err(st[1], (y_ref ** 2).sum(axis=0)) < 1e-4
+    # the engine's form: weights transposed for a whole table of layers in one launch, then handed to the forward -- bit-identical
+    # (this case's matrix plus a second, ragged one in the same table; the copy is ignored where another kernel family runs)
+    w2 = rng.normal(0, 1, (37, 50)).astype(np.float32)
+    dw2, dwt, dwt2 = ctx.array(w2), ctx.zeros((n, k)), ctx.zeros((50, 37))
+    table = ctx.array(np.array([[dw_.ptr, dwt.ptr, k, n], [dw2.ptr, dwt2.ptr, 37, 50]], dtype=np.int64))
+    ctx.call("ssdseg_transpose_batch", table, 2, max(-(-k // 32) * -(-n // 32), 4), k * n + 37 * 50)
+    assert np.array_equal(dwt.download(), wgt.T) and np.array_equal(dwt2.download(), w2.T)
+    dy2, stats2 = ctx.empty((m, n)), ctx.empty((nparts, 2, n))
+    ctx.call("ssdseg_pwconv_fwd_wt", H.view(dx_, dsc, dsh, act), k, dw_, dwt, dy2, n, m, k, n, stats2)
+    assert np.array_equal(dy2.download(), y) and np.array_equal(stats2.download(), stats.download())
     # identity view, no stats
     ctx.call("ssdseg_pwconv_fwd", H.view(dx_), k, dw_, dy_, n, m, k, n, None)
     assert rel_err(dy_.download(), x.astype(np.float64) @ wgt.astype(np.float64)) < 2e-5

@@ -43,7 +43,9 @@ def gview_inputs(rng, shape, act):
                                             (2, 17, 33, 40, 200),   # odd number of 8-channel steps; two 100-column tiles of a 128-wide block
                                             (1, 8, 32, 12, 16),     # cin not a multiple of 8: the implicit-GEMM forward, halo-tile backward
                                             (2, 6, 64, 80, 72),     # even h, w a multiple of 32: the Winograd weight gradient ("wino"), partial 64-channel patches, 3 splits
-                                            (3, 2, 32, 64, 64)])    # one tile row per image: every step crosses an image border of the padded copy
+                                            (3, 2, 32, 64, 64),     # one tile row per image: every step crosses an image border of the padded copy
+                                            (5, 4, 32, 130, 70),    # Winograd weight gradient: 6 patches x 10 steps = 2 full chunks of 4 + a 2-step tail dealt to 3 blocks, each working on two patches in turn
+                                            (9, 2, 32, 72, 136)])   # ... 9 steps: a 1-step tail, one tail block walks four patches, the other two
 # kernel family: "narrow" = cout <= 8 as tap-expanded pointwise GEMMs (default for those shapes); "tile" = the halo-tile kernels
 # (conv3_tile.h); "wino" = the Winograd F(2x2, 3x3) kernels forced at every size (conv3_wino.h, default for the large layers: same
 # tolerance -- its transforms are additions and halvings); "gemm" = the implicit-GEMM kernels
