@@ -243,6 +243,14 @@ int ssdseg_conv3x3_bwd_weight_saved(ssdseg_ctx* ctx, const float* xsaved, const 
                                     int cout);
 int ssdseg_conv3x3_bwd_data(ssdseg_ctx* ctx, const ssdseg_gview* dy, const float* w, float* dx, int ldx, int n,
                             int h, int wdt, int cin, int cout, int accumulate);
+/* The same plus the BatchNormalization backward of the layer that FEEDS this conv (in = that BN's view of the conv input; the
+ * decoder's 256 -> output_channels conv behind sepconv-batchnorm, blocks.py:121-126): for the narrow, tap-expanded form the sums
+ * sum(mask*dx), sum(mask*dx*xhat) ride in the epilogue of the GEMM that writes dx; other shapes run ssdseg_conv3x3_bwd_data
+ * followed by ssdseg_bn_bwd_reduce.  Only valid when this conv is the ONLY consumer of the BN output (dx is overwritten).
+ * Outputs as ssdseg_bn_bwd_reduce (dgamma, dbeta may be NULL). */
+int ssdseg_conv3x3_bwd_data_bn(ssdseg_ctx* ctx, const ssdseg_view* in, const ssdseg_gview* dy, const float* w, float* dx, int ldx,
+                               int n, int h, int wdt, int cin, int cout, const float* in_mean, const float* in_invstd,
+                               float* in_dgamma, float* in_dbeta, float* in_k1, float* in_k0);
 int ssdseg_conv3x3_bwd_weight(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssdseg_gview* dy, float* dw,
                               int n, int h, int wdt, int cin, int cout);
 
@@ -297,6 +305,16 @@ int ssdseg_mask_head_fwd(ssdseg_ctx* ctx, const float* logits, int n, int h, int
 /* dlogits (low resolution) = upsample^T( softmax'( dL/dp ) ), dL/dp = -loss_scale * w_c * y / p inside the clip */
 int ssdseg_mask_head_bwd(ssdseg_ctx* ctx, const float* logits, int n, int h, int wdt, int c, int fy, int fx,
                          const float* y_true, const float* class_weights_host, float loss_scale, float* dlogits);
+/* The same head trained with the reference's dice / dice_square losses (losses.py:175-264; squared != 0: dice_square).  The
+ * forward also leaves, per image, the eight coefficients the backward needs (coef [n][8]: A_c = -2 w_c / (T_c + eps),
+ * B_c = w_c (2 I_c + eps) / (T_c + eps)^2 with I_c = sum y p, T_c = sum (y + p) [sum (y^2 + p^2)] over the image's pixels), so
+ * that dL/dp_c = A_c y_c + B_c [2 p_c] is formed per pixel in the backward kernels exactly like the cross-entropy's.
+ * prob, loss may be NULL (not both loss and coef). */
+int ssdseg_mask_head_fwd_dice(ssdseg_ctx* ctx, const float* logits, int n, int h, int wdt, int c, int fy, int fx,
+                              const float* y_true, const float* class_weights_host, int squared, float* prob, float* loss,
+                              float* coef);
+int ssdseg_mask_head_bwd_dice(ssdseg_ctx* ctx, const float* logits, int n, int h, int wdt, int c, int fy, int fx,
+                              const float* y_true, const float* coef, int squared, float loss_scale, float* dlogits);
 /* SSD head plumbing: Reshape(-1, 4) + Concatenate(axis=1) (blocks.py:155; models.py:256,271).  Forward: the activated
  * head tensor of one feature map, in[b][in_img_elems] (channel of element r = r % c), is written to
  * out[b][out_off_elems + r] of a buffer with out_img_elems floats per image.  reverse != 0 copies the other way

@@ -1841,29 +1841,12 @@ int ssdseg_pwconv_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssd
 // dx + dW of a pointwise conv plus the BatchNorm backward of the layer feeding it (the depthwise BN in front of a project conv):
 // the backward-data kernel's float4 epilogue reduces sum(mask*dx), sum(mask*dx*xhat) while it stores dx.  Only valid when this
 // conv is the ONLY consumer of that BatchNorm's output.  Falls back to the separate reduction pass for unaligned tensors.
-int ssdseg_pwconv_bwd_bn(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssdseg_gview* dy, int ldy, const float* w, float* dx,
-                         int lddx, float* dw, int m, int k, int n, const float* in_mean, const float* in_invstd, float* in_dgamma,
-                         float* in_dbeta, float* in_k1, float* in_k0) {
-    SSDSEG_ARG(ctx != nullptr, 1);
-    SSDSEG_ARG(in != nullptr && in->x != nullptr && in->scale != nullptr && in->shift != nullptr, 2);
-    SSDSEG_ARG(ldx >= k && ldx % 4 == 0, 3);
-    SSDSEG_ARG(dy != nullptr && dy->g != nullptr, 4);
-    SSDSEG_ARG(dy->scale == nullptr || (dy->y && dy->shift && dy->k1 && dy->k0), 4);
-    SSDSEG_ARG(ldy >= n && ldy % 4 == 0, 5);
-    SSDSEG_ARG(w != nullptr, 6);
-    SSDSEG_ARG(dx != nullptr, 7);
-    SSDSEG_ARG(lddx >= k, 8);
-    SSDSEG_ARG(dw != nullptr, 9);
-    SSDSEG_ARG(m > 0, 10);
-    SSDSEG_ARG(k > 0 && k % 4 == 0, 11);
-    SSDSEG_ARG(n > 0 && n % 4 == 0, 12);
-    SSDSEG_ARG(in_mean != nullptr && in_invstd != nullptr, 13);
-    SSDSEG_ARG(in_k1 != nullptr && in_k0 != nullptr, 17);
-    // dW first, on the side stream (it only reads)
-    const bool side = ssdseg_side_begin(ctx);
-    int rc = ssdseg_pwconv_bwd_weight(ctx, in, ldx, dy, ldy, dw, m, k, n);
-    if (side) ssdseg_side_end(ctx);
-    if (rc) return rc;
+// dx = dy * w^T plus the BatchNormalization backward of the layer that feeds this conv (sums in the GEMM epilogue); shared by
+// ssdseg_pwconv_bwd_bn and the tap-expanded form of the narrow 3x3 conv (ssdseg_conv3x3_bwd_data_bn)
+static int pwconv_bwd_data_bn(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssdseg_gview* dy, int ldy, const float* w, float* dx,
+                              int lddx, int m, int k, int n, const float* in_mean, const float* in_invstd, float* in_dgamma,
+                              float* in_dbeta, float* in_k1, float* in_k0) {
+    int rc = 0;
     const bool aligned = lddx % 4 == 0 && ((uintptr_t)dx & 15) == 0 && ((uintptr_t)in->x & 15) == 0;
     const char* benv = getenv("SSDSEG_NO_BN_EPILOGUE");
     if (!aligned || (benv != nullptr && benv[0] == '1')) {
@@ -1941,6 +1924,32 @@ int ssdseg_pwconv_bwd_bn(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const 
     }
     SSDSEG_LAUNCH_CHECK();
     return ssdseg_bn_bwd_finalize_launch(ctx, a.bnpart, nparts, k, (double)m, in->scale, in_mean, in_invstd, in_dgamma, in_dbeta, in_k1, in_k0);
+}
+
+int ssdseg_pwconv_bwd_bn(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssdseg_gview* dy, int ldy, const float* w, float* dx,
+                         int lddx, float* dw, int m, int k, int n, const float* in_mean, const float* in_invstd, float* in_dgamma,
+                         float* in_dbeta, float* in_k1, float* in_k0) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(in != nullptr && in->x != nullptr && in->scale != nullptr && in->shift != nullptr, 2);
+    SSDSEG_ARG(ldx >= k && ldx % 4 == 0, 3);
+    SSDSEG_ARG(dy != nullptr && dy->g != nullptr, 4);
+    SSDSEG_ARG(dy->scale == nullptr || (dy->y && dy->shift && dy->k1 && dy->k0), 4);
+    SSDSEG_ARG(ldy >= n && ldy % 4 == 0, 5);
+    SSDSEG_ARG(w != nullptr, 6);
+    SSDSEG_ARG(dx != nullptr, 7);
+    SSDSEG_ARG(lddx >= k, 8);
+    SSDSEG_ARG(dw != nullptr, 9);
+    SSDSEG_ARG(m > 0, 10);
+    SSDSEG_ARG(k > 0 && k % 4 == 0, 11);
+    SSDSEG_ARG(n > 0 && n % 4 == 0, 12);
+    SSDSEG_ARG(in_mean != nullptr && in_invstd != nullptr, 13);
+    SSDSEG_ARG(in_k1 != nullptr && in_k0 != nullptr, 17);
+    // dW first, on the side stream (it only reads)
+    const bool side = ssdseg_side_begin(ctx);
+    int rc = ssdseg_pwconv_bwd_weight(ctx, in, ldx, dy, ldy, dw, m, k, n);
+    if (side) ssdseg_side_end(ctx);
+    if (rc) return rc;
+    return pwconv_bwd_data_bn(ctx, in, ldx, dy, ldy, w, dx, lddx, m, k, n, in_mean, in_invstd, in_dgamma, in_dbeta, in_k1, in_k0);
 }
 
 int ssdseg_pwconv_bwd_weight(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssdseg_gview* dy, int ldy, float* dw,
@@ -2167,6 +2176,51 @@ int ssdseg_conv3x3_bwd_weight_saved(ssdseg_ctx* ctx, const float* xsaved, const 
     if (rc) return rc;
     SSDSEG_ARG(need > 0, 5);
     return conv3_wino_wgrad_launch(ctx, nullptr, cin, dy, dw, n, h, wdt, cin, cout, xsaved);
+}
+
+int ssdseg_conv3x3_bwd_data_bn(ssdseg_ctx* ctx, const ssdseg_view* in, const ssdseg_gview* dy, const float* w, float* dx, int ldx, int n,
+                               int h, int wdt, int cin, int cout, const float* in_mean, const float* in_invstd, float* in_dgamma,
+                               float* in_dbeta, float* in_k1, float* in_k0) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(in != nullptr && in->x != nullptr && in->scale != nullptr && in->shift != nullptr, 2);
+    SSDSEG_ARG(dy != nullptr && dy->g != nullptr, 3);
+    SSDSEG_ARG(dy->scale == nullptr || (dy->y && dy->shift && dy->k1 && dy->k0), 3);
+    SSDSEG_ARG(w != nullptr, 4);
+    SSDSEG_ARG(dx != nullptr, 5);
+    SSDSEG_ARG(ldx >= cin && ldx % 4 == 0, 6);
+    SSDSEG_ARG(n > 0 && h > 0 && wdt > 0, 7);
+    SSDSEG_ARG(cin > 0 && cin % 4 == 0, 10);
+    SSDSEG_ARG(cout > 0 && cout % 4 == 0, 11);
+    SSDSEG_ARG(in_mean != nullptr && in_invstd != nullptr, 12);
+    SSDSEG_ARG(in_k1 != nullptr && in_k0 != nullptr, 16);
+    const long long m = (long long)n * h * wdt;
+    if (conv3_narrow(cin, cout)) {
+        // tap-expanded form: dz[m][tap][o] = dy[m - d(tap)][o], then dx = dz * W2^T is a pointwise GEMM whose float4 epilogue holds the dx
+        // tile and reads the matching tile of the raw input -- that BN's sums ride there (the 256 -> 4 logits conv of the decoder:
+        // one pass over the 614,400 x 256 gradient and its raw tensor less)
+        const int nc = 9 * cout, cv = cout / 4;
+        const size_t wb = align256((size_t)cin * nc * sizeof(float)), zb = align256((size_t)m * nc * sizeof(float));
+        void* ws;
+        int rc = conv3n_scratch(ctx, wb + zb, &ws);
+        if (rc) return rc;
+        float* w2 = (float*)ws;
+        float* dz = (float*)((char*)ws + wb);
+        SSDSEG_LAUNCH(ctx, 8.0 * 9 * cin * cout, 0.0, conv3n_pack_w_kernel, dim3(cdiv(9 * cin * cout, 256)), dim3(256), 0, w, w2, cin, cout, 0);
+        SSDSEG_LAUNCH_CHECK();
+        const long long tot = m * 9 * cv;
+        SSDSEG_LAUNCH(ctx, 4.0 * m * (nc + (dy->scale ? 2.0 : 1.0) * cout), 0.0, conv3n_shift_kernel, dim3((unsigned)((tot + 255) / 256 < 8192 ? (tot + 255) / 256 : 8192)),
+                      dim3(256), 0, dy->g, dy->y, dy->scale, dy->shift, dy->k1, dy->k0, dy->act, dz, n, h, wdt, cv);
+        SSDSEG_LAUNCH_CHECK();
+        ssdseg_gview idv{};
+        idv.g = dz;
+        ctx->ws_reserved += wb + zb;
+        rc = pwconv_bwd_data_bn(ctx, in, ldx, &idv, nc, w2, dx, ldx, (int)m, cin, nc, in_mean, in_invstd, in_dgamma, in_dbeta, in_k1, in_k0);
+        ctx->ws_reserved -= wb + zb;
+        return rc;
+    }
+    int rc = ssdseg_conv3x3_bwd_data(ctx, dy, w, dx, ldx, n, h, wdt, cin, cout, 0);
+    if (rc) return rc;
+    return ssdseg_bn_bwd_reduce(ctx, dx, ldx, in->x, ldx, (int)m, cin, in->scale, in->shift, in_mean, in_invstd, in->act, in_dgamma, in_dbeta, in_k1, in_k0);
 }
 
 int ssdseg_conv3x3_bwd_data(ssdseg_ctx* ctx, const ssdseg_gview* dy, const float* w, float* dx, int ldx, int n, int h, int wdt,

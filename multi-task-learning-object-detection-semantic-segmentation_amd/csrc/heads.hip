@@ -271,6 +271,88 @@ __device__ __forceinline__ float4 up_logits(const float* __restrict__ logits, lo
 __device__ __forceinline__ float clip_log(float p) { return logf(fminf(fmaxf(p, KEPS), 1.f - KEPS)); }
 __device__ __forceinline__ float inside(float p) { return (p >= KEPS && p <= 1.f - KEPS) ? 1.f : 0.f; }
 
+// dL/dp of one pixel.  mode 0: weighted cross-entropy, -w_c y_c / clip(p_c) inside the clip interval, 0 outside (App. B.6);
+// mode 1 / 2: dice / dice_square (reference losses.py:204-216, 250-262): with the per-image sums I_c = sum y p, T_c = sum (y + p)
+// [sum (y^2 + p^2)],  dL/dp_c = A_c y_c + B_c [2 p_c],  A_c = -2 w_c / (T_c + eps),  B_c = w_c (2 I_c + eps) / (T_c + eps)^2
+// (cA, cB: written per image by mask_dice_final_kernel).
+__device__ __forceinline__ float4 mask_dp(int mode, float4 cw, float4 y, float4 pr, float4 cA, float4 cB) {
+    float4 dp;
+    if (mode == 0) {
+        dp.x = -cw.x * y.x / fminf(fmaxf(pr.x, KEPS), 1.f - KEPS) * inside(pr.x);
+        dp.y = -cw.y * y.y / fminf(fmaxf(pr.y, KEPS), 1.f - KEPS) * inside(pr.y);
+        dp.z = -cw.z * y.z / fminf(fmaxf(pr.z, KEPS), 1.f - KEPS) * inside(pr.z);
+        dp.w = -cw.w * y.w / fminf(fmaxf(pr.w, KEPS), 1.f - KEPS) * inside(pr.w);
+    } else {
+        const float4 t = mode == 2 ? make_float4(2.f * pr.x, 2.f * pr.y, 2.f * pr.z, 2.f * pr.w) : f4(1.f);
+        dp.x = fmaf(cA.x, y.x, cB.x * t.x);
+        dp.y = fmaf(cA.y, y.y, cB.y * t.y);
+        dp.z = fmaf(cA.z, y.z, cB.z * t.z);
+        dp.w = fmaf(cA.w, y.w, cB.w * t.w);
+    }
+    return dp;
+}
+
+// dice / dice_square forward: probabilities (optional) and per-block partial sums (I_c, T_c); grid (blocks_per_image, n),
+// partial[n][blocks_per_image][8]
+__global__ void __launch_bounds__(256) mask_head_fwd_dice_kernel(const float* __restrict__ logits, int h, int w, int fy, int fx,
+                                                                 const float* __restrict__ y_true, int squared, float* __restrict__ prob,
+                                                                 float* __restrict__ partial) {
+    __shared__ float red[8][256];
+    const int ho = h * fy, wo = w * fx;
+    const long long npix = (long long)ho * wo;
+    const long long img = blockIdx.y;
+    const float ify = 1.f / (float)fy, ifx = 1.f / (float)fx;
+    float4 si = f4(0.f), st = f4(0.f);
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long long)gridDim.x * blockDim.x) {
+        const int ox = (int)(p % wo), oy = (int)(p / wo);
+        const float4 pr = softmax4(up_logits(logits, img, h, w, oy, ox, ify, ifx));
+        const long long off = (img * npix + p) * 4;
+        if (prob) st4(prob + off, pr);
+        const float4 y = ld4(y_true + off);
+        si.x = fmaf(y.x, pr.x, si.x); si.y = fmaf(y.y, pr.y, si.y); si.z = fmaf(y.z, pr.z, si.z); si.w = fmaf(y.w, pr.w, si.w);
+        if (squared) {
+            st.x += fmaf(y.x, y.x, pr.x * pr.x); st.y += fmaf(y.y, y.y, pr.y * pr.y); st.z += fmaf(y.z, y.z, pr.z * pr.z); st.w += fmaf(y.w, y.w, pr.w * pr.w);
+        } else {
+            st.x += y.x + pr.x; st.y += y.y + pr.y; st.z += y.z + pr.z; st.w += y.w + pr.w;
+        }
+    }
+    const int t = threadIdx.x;
+    red[0][t] = si.x; red[1][t] = si.y; red[2][t] = si.z; red[3][t] = si.w;
+    red[4][t] = st.x; red[5][t] = st.y; red[6][t] = st.z; red[7][t] = st.w;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s)
+#pragma unroll
+            for (int v = 0; v < 8; ++v) red[v][t] += red[v][t + s];
+        __syncthreads();
+    }
+    if (t < 8) partial[(img * gridDim.x + blockIdx.x) * 8 + t] = red[t][0];
+}
+
+// per image: I_c, T_c (partials summed in index order, double), the loss, and the backward coefficients coef[img] = (A_0..3, B_0..3)
+__global__ void mask_dice_final_kernel(const float* __restrict__ partial, int nblk, int n, float4 cw, float* __restrict__ loss,
+                                       float* __restrict__ coef) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < nblk; ++b)
+#pragma unroll
+        for (int v = 0; v < 8; ++v) s[v] += (double)partial[((long long)i * nblk + b) * 8 + v];
+    const double w[4] = {cw.x, cw.y, cw.z, cw.w};
+    const double eps = (double)KEPS;
+    double l = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const double den = s[4 + c] + eps, num = 2.0 * s[c] + eps;
+        l += w[c] * (1.0 - num / den);
+        if (coef != nullptr) {
+            coef[i * 8 + c] = (float)(-2.0 * w[c] / den);
+            coef[i * 8 + 4 + c] = (float)(w[c] * num / (den * den));
+        }
+    }
+    if (loss != nullptr) loss[i] = (float)l;
+}
+
 // grid (blocks_per_image, n); partial[n][blocks_per_image] per-image loss partials
 __global__ void __launch_bounds__(256) mask_head_fwd_kernel(const float* __restrict__ logits, int h, int w, int fy, int fx,
                                                             const float* __restrict__ y_true, float4 cw, float* __restrict__ prob,
@@ -313,7 +395,7 @@ __global__ void mask_loss_final_kernel(const float* __restrict__ partial, int nb
 // dlogits(low res) = sum over the full-res pixels that interpolate from it of weight * dz, dz = softmax'(dL/dp)
 __global__ void __launch_bounds__(256) mask_head_bwd_kernel(const float* __restrict__ logits, int n, int h, int w, int fy, int fx,
                                                             const float* __restrict__ y_true, float4 cw, float loss_scale,
-                                                            float* __restrict__ dlogits) {
+                                                            float* __restrict__ dlogits, int mode, const float* __restrict__ coef) {
     const int ho = h * fy, wo = w * fx;
     const long long total = (long long)n * h * w;
     const float ify = 1.f / (float)fy, ifx = 1.f / (float)fx;
@@ -326,6 +408,7 @@ __global__ void __launch_bounds__(256) mask_head_bwd_kernel(const float* __restr
         oy0 = oy0 < 0 ? 0 : oy0; ox0 = ox0 < 0 ? 0 : ox0;
         oy1 = oy1 > ho - 1 ? ho - 1 : oy1; ox1 = ox1 > wo - 1 ? wo - 1 : ox1;
         float4 acc = f4(0.f);
+        const float4 cA = mode != 0 ? ld4(coef + img * 8) : f4(0.f), cB = mode != 0 ? ld4(coef + img * 8 + 4) : f4(0.f);
         for (int oy = oy0; oy <= oy1; ++oy) {
             const float wy = lerp_weight(oy, iy, h, ify);
             if (wy == 0.f) continue;
@@ -334,12 +417,7 @@ __global__ void __launch_bounds__(256) mask_head_bwd_kernel(const float* __restr
                 if (wx == 0.f) continue;
                 const float4 pr = softmax4(up_logits(logits, img, h, w, oy, ox, ify, ifx));
                 const float4 y = ld4(y_true + ((img * ho + oy) * wo + ox) * 4);
-                // dL/dp_c = -w_c y_c / clip(p_c) inside the clip interval, 0 outside (App. B.6)
-                float4 dp;
-                dp.x = -cw.x * y.x / fminf(fmaxf(pr.x, KEPS), 1.f - KEPS) * inside(pr.x);
-                dp.y = -cw.y * y.y / fminf(fmaxf(pr.y, KEPS), 1.f - KEPS) * inside(pr.y);
-                dp.z = -cw.z * y.z / fminf(fmaxf(pr.z, KEPS), 1.f - KEPS) * inside(pr.z);
-                dp.w = -cw.w * y.w / fminf(fmaxf(pr.w, KEPS), 1.f - KEPS) * inside(pr.w);
+                const float4 dp = mask_dp(mode, cw, y, pr, cA, cB);
                 const float dot = dp.x * pr.x + dp.y * pr.y + dp.z * pr.z + dp.w * pr.w;
                 const float wgt = wy * wx * loss_scale;
                 acc.x = fmaf(wgt, pr.x * (dp.x - dot), acc.x);
@@ -360,7 +438,7 @@ __global__ void __launch_bounds__(256) mask_head_bwd_kernel(const float* __restr
 template <int F, int TL>
 __global__ void __launch_bounds__(TL * TL) mask_head_bwd_tile_kernel(const float* __restrict__ logits, int n, int h, int w,
                                                                        const float* __restrict__ y_true, float4 cw, float loss_scale,
-                                                                       float* __restrict__ dlogits) {
+                                                                       float* __restrict__ dlogits, int mode, const float* __restrict__ coef) {
     constexpr int R = TL * F + F;                    // full-resolution rows / columns a tile can draw from (F/2 + F/2 beyond each side)
     extern __shared__ float4 dz[];                    // [R][R]
     const int ho = h * F, wo = w * F;
@@ -375,6 +453,7 @@ __global__ void __launch_bounds__(TL * TL) mask_head_bwd_tile_kernel(const float
     // o in [i*F - F/2, i*F + F + F/2 - 1]; a tile of TL pixels therefore draws from R = TL*F + F of them, starting at i0*F - F/2
     // (the candidate loops below run a little wider and skip the zero weights before touching LDS)
     const int oyb = iy0 * F - F / 2, oxb = ix0 * F - F / 2;
+    const float4 cA = mode != 0 ? ld4(coef + img * 8) : f4(0.f), cB = mode != 0 ? ld4(coef + img * 8 + 4) : f4(0.f);
     for (int i = threadIdx.x; i < R * R; i += TL * TL) {
         const int ry = i / R, rx = i - ry * R;
         const int oy = oyb + ry, ox = oxb + rx;
@@ -382,11 +461,7 @@ __global__ void __launch_bounds__(TL * TL) mask_head_bwd_tile_kernel(const float
         if (oy >= 0 && oy < ho && ox >= 0 && ox < wo) {
             const float4 pr = softmax4(up_logits(logits, img, h, w, oy, ox, inv, inv));
             const float4 y = ld4(y_true + ((img * ho + oy) * wo + ox) * 4);
-            float4 dp;
-            dp.x = -cw.x * y.x / fminf(fmaxf(pr.x, KEPS), 1.f - KEPS) * inside(pr.x);
-            dp.y = -cw.y * y.y / fminf(fmaxf(pr.y, KEPS), 1.f - KEPS) * inside(pr.y);
-            dp.z = -cw.z * y.z / fminf(fmaxf(pr.z, KEPS), 1.f - KEPS) * inside(pr.z);
-            dp.w = -cw.w * y.w / fminf(fmaxf(pr.w, KEPS), 1.f - KEPS) * inside(pr.w);
+            const float4 dp = mask_dp(mode, cw, y, pr, cA, cB);
             const float dot = dp.x * pr.x + dp.y * pr.y + dp.z * pr.z + dp.w * pr.w;
             v = make_float4(pr.x * (dp.x - dot), pr.y * (dp.y - dot), pr.z * (dp.z - dot), pr.w * (dp.w - dot));
         }
@@ -671,6 +746,51 @@ int ssdseg_mask_head_fwd(ssdseg_ctx* ctx, const float* logits, int n, int h, int
     return 0;
 }
 
+static int mask_head_bwd_launch(ssdseg_ctx* ctx, const float* logits, int n, int h, int wdt, int fy, int fx, const float* y_true, const float* cwh,
+                                float loss_scale, float* dlogits, int mode, const float* coef);
+
+int ssdseg_mask_head_fwd_dice(ssdseg_ctx* ctx, const float* logits, int n, int h, int wdt, int c, int fy, int fx, const float* y_true,
+                              const float* class_weights_host, int squared, float* prob, float* loss, float* coef) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(logits != nullptr, 2);
+    SSDSEG_ARG(n > 0 && h > 0 && wdt > 0, 3);
+    SSDSEG_ARG(c == 4, 6);
+    SSDSEG_ARG(fy >= 1 && fx >= 1, 7);
+    SSDSEG_ARG(y_true != nullptr, 9);
+    SSDSEG_ARG(class_weights_host != nullptr, 10);
+    SSDSEG_ARG(loss != nullptr || coef != nullptr, 13);
+    float cwh[4];
+    memcpy(cwh, class_weights_host, sizeof(cwh));
+    const long long npix = (long long)h * fy * wdt * fx;
+    int nblk = (int)((npix + 256 * 8 - 1) / (256 * 8));
+    if (nblk > 256) nblk = 256;
+    if (nblk < 1) nblk = 1;
+    void* ws;
+    int rc = ssdseg_workspace(ctx, (size_t)n * nblk * 8 * sizeof(float), &ws);
+    if (rc) return rc;
+    SSDSEG_LAUNCH(ctx, 16.0 * n * npix * (1 + (prob ? 1 : 0)), 0.0, mask_head_fwd_dice_kernel, dim3(nblk, n), dim3(256), 0, logits, h, wdt, fy, fx,
+                  y_true, squared ? 1 : 0, prob, (float*)ws);
+    SSDSEG_LAUNCH_CHECK();
+    SSDSEG_LAUNCH(ctx, 32.0 * n * nblk, 0.0, mask_dice_final_kernel, dim3(cdiv(n, 64)), dim3(64), 0, (const float*)ws, nblk, n,
+                  make_float4(cwh[0], cwh[1], cwh[2], cwh[3]), loss, coef);
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+int ssdseg_mask_head_bwd_dice(ssdseg_ctx* ctx, const float* logits, int n, int h, int wdt, int c, int fy, int fx, const float* y_true,
+                              const float* coef, int squared, float loss_scale, float* dlogits) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(logits != nullptr, 2);
+    SSDSEG_ARG(n > 0 && h > 0 && wdt > 0, 3);
+    SSDSEG_ARG(c == 4, 6);
+    SSDSEG_ARG(fy >= 1 && fx >= 1, 7);
+    SSDSEG_ARG(y_true != nullptr, 9);
+    SSDSEG_ARG(coef != nullptr, 10);
+    SSDSEG_ARG(dlogits != nullptr, 13);
+    const float zero[4] = {0.f, 0.f, 0.f, 0.f};
+    return mask_head_bwd_launch(ctx, logits, n, h, wdt, fy, fx, y_true, zero, loss_scale, dlogits, squared ? 2 : 1, coef);
+}
+
 int ssdseg_mask_head_bwd(ssdseg_ctx* ctx, const float* logits, int n, int h, int wdt, int c, int fy, int fx, const float* y_true,
                          const float* class_weights_host, float loss_scale, float* dlogits) {
     SSDSEG_ARG(ctx != nullptr, 1);
@@ -683,6 +803,11 @@ int ssdseg_mask_head_bwd(ssdseg_ctx* ctx, const float* logits, int n, int h, int
     SSDSEG_ARG(dlogits != nullptr, 12);
     float cwh[4];
     memcpy(cwh, class_weights_host, sizeof(cwh));
+    return mask_head_bwd_launch(ctx, logits, n, h, wdt, fy, fx, y_true, cwh, loss_scale, dlogits, 0, nullptr);
+}
+
+static int mask_head_bwd_launch(ssdseg_ctx* ctx, const float* logits, int n, int h, int wdt, int fy, int fx, const float* y_true, const float* cwh,
+                                float loss_scale, float* dlogits, int mode, const float* coef) {
     const long long total = (long long)n * h * wdt;
     const char* mt = getenv("SSDSEG_MASK_BWD");       // "gather": the one-thread-per-pixel kernel (A/B runs, parity tests)
     if (fy == 4 && fx == 4 && !(mt != nullptr && !strcmp(mt, "gather"))) {
@@ -695,12 +820,12 @@ int ssdseg_mask_head_bwd(ssdseg_ctx* ctx, const float* logits, int n, int h, int
             configured = true;
         }
         SSDSEG_LAUNCH(ctx, 16.0 * n * h * fy * wdt * fx, 0.0, (mask_head_bwd_tile_kernel<F, TL>), dim3((unsigned)blocks), dim3(TL * TL), R * R * sizeof(float4), logits, n,
-                      h, wdt, y_true, make_float4(cwh[0], cwh[1], cwh[2], cwh[3]), loss_scale, dlogits);
+                      h, wdt, y_true, make_float4(cwh[0], cwh[1], cwh[2], cwh[3]), loss_scale, dlogits, mode, coef);
         SSDSEG_LAUNCH_CHECK();
         return 0;
     }
     SSDSEG_LAUNCH(ctx, 16.0 * n * h * fy * wdt * fx, 0.0, mask_head_bwd_kernel, dim3(ew_blocks(total, 256)), dim3(256), 0, logits, n, h, wdt,
-                  fy, fx, y_true, make_float4(cwh[0], cwh[1], cwh[2], cwh[3]), loss_scale, dlogits);
+                  fy, fx, y_true, make_float4(cwh[0], cwh[1], cwh[2], cwh[3]), loss_scale, dlogits, mode, coef);
     SSDSEG_LAUNCH_CHECK();
     return 0;
 }

@@ -289,6 +289,7 @@ class Conv3Op(Op):
         # large layers (Winograd kernels): the forward leaves act(BN(x)) in a zero-bordered copy which the weight gradient reads
         # again, so the view is applied once per step (ssdseg_conv3x3_fwd_saved / _bwd_weight_saved)
         self.xsaved = None
+        self.fuse_input_bn = False   # set by the lowering (narrow convs that are the only consumer of a BatchNorm output)
         if eng.training:
             need = C.c_longlong()
             H._check(eng.ctx.lib.ssdseg_conv3x3_saved_floats(s.n, s.h, s.w, s.c, out.c, C.byref(need)), "ssdseg_conv3x3_saved_floats")
@@ -326,7 +327,15 @@ class Conv3Op(Op):
         finally:
             if side:
                 self.e.ctx.side(False)
-        if s.need_grad:
+        b = self.inp.bn
+        if (self.fuse_input_bn and b is not None and s.need_grad and s.pending is None and not s._written()):
+            # sole consumer of a BatchNorm(+ReLU) output (the decoder's logits conv behind sepconv-batchnorm): that BN's backward
+            # sums ride in the epilogue of the GEMM that writes dx
+            dx, _ = s.grad_slot()
+            self.e.ctx.call("ssdseg_conv3x3_bwd_data_bn", self.inp.view(), gv, self.w, dx, s.ld, s.n, s.h, s.w, s.c, self.out.c,
+                            b.mean, b.invstd, b.dgamma, b.dbeta, b.k1, b.k0)
+            b.bwd_done = True
+        elif s.need_grad:
             dx, acc = s.grad_slot()
             self.e.ctx.call("ssdseg_conv3x3_bwd_data", gv, self.w, dx, s.ld, s.n, s.h, s.w, s.c, self.out.c, acc)
 
@@ -547,11 +556,18 @@ class MaskHeadOp(Op):
         self.class_weights: Optional[H.DeviceBuffer] = None
         self.loss: Optional[H.DeviceBuffer] = None
         self.loss_scale = 0.0
+        self.kind = "cross_entropy"                       # | "dice" | "dice_square" (reference losses.py:175-307)
+        self.coef: Optional[H.DeviceBuffer] = None        # dice: per-image backward coefficients left by the forward
 
     def fwd(self):
         s = self.logits.store
+        prob = self.prob.buf if self.prob is not None else None
+        if self.loss is not None and self.kind != "cross_entropy":
+            self.e.ctx.call("ssdseg_mask_head_fwd_dice", s.buf, s.n, s.h, s.w, s.c, self.fy, self.fx, self.y_true, self.class_weights,
+                            1 if self.kind == "dice_square" else 0, prob, self.loss, self.coef)
+            return
         self.e.ctx.call("ssdseg_mask_head_fwd", s.buf, s.n, s.h, s.w, s.c, self.fy, self.fx, self.y_true if self.loss is not None else None,
-                        self.class_weights, self.prob.buf if self.prob is not None else None, self.loss)
+                        self.class_weights, prob, self.loss)
 
     def bwd(self):
         if self.loss is None:
@@ -559,6 +575,10 @@ class MaskHeadOp(Op):
         s = self.logits.store
         g, acc = s.grad_slot()
         assert acc == 0
+        if self.kind != "cross_entropy":
+            self.e.ctx.call("ssdseg_mask_head_bwd_dice", s.buf, s.n, s.h, s.w, s.c, self.fy, self.fx, self.y_true, self.coef,
+                            1 if self.kind == "dice_square" else 0, self.loss_scale, g)
+            return
         self.e.ctx.call("ssdseg_mask_head_bwd", s.buf, s.n, s.h, s.w, s.c, self.fy, self.fx, self.y_true, self.class_weights, self.loss_scale, g)
 
 
@@ -1016,6 +1036,10 @@ class Engine:
             assert layer.strides == (1, 1) and not layer.use_bias and layer.dilation_rate == (1, 1)
             st = self._out_store(layer, out_t.shape)
             op = self._emit(Conv3Op(self, layer, v, st))
+            src = layer.inbound[0]
+            # the narrow (<= 8 filters) form writes dx from a pointwise GEMM: the producer BN's backward sums can ride there
+            op.fuse_input_bn = (v.bn is not None and layer.filters <= 8 and v.store.parent is None and v.store.ld == v.store.c
+                                and len(self.cons.get(id(src), [])) == 1 and id(src) not in {id(t) for t in self.model.outputs})
         else:
             raise NotImplementedError(f"{layer.name}: Conv2D {layer.kernel_size} stride {layer.strides}")
         op.out_val = Val(st)
@@ -1226,10 +1250,12 @@ class Engine:
             w = float(loss_weights.get(name, 1.0))
             v = self.vals[id(t)]
             if "mask_head" in v.meta:
-                if getattr(fn, "loss_kind", None) != "cross_entropy":
-                    raise NotImplementedError("the fused mask head trains with ssdseglib.losses.cross_entropy(weights); dice losses are "
-                                              "available as standalone functions")
+                if getattr(fn, "loss_kind", None) not in ("cross_entropy", "dice", "dice_square"):
+                    raise NotImplementedError(f"loss for output {name}: the mask head trains with ssdseglib.losses.cross_entropy / dice / "
+                                              "dice_square")
                 op: MaskHeadOp = v.meta["mask_head"]
+                op.kind = fn.loss_kind
+                op.coef = self.ctx.empty((b, 8)) if op.kind != "cross_entropy" else None
                 s = op.logits.store
                 op.y_true = self.ctx.empty((b, s.h * op.fy, s.w * op.fx, s.c))
                 op.class_weights = (C.c_float * 4)(*[float(x) for x in fn.classes_weights])

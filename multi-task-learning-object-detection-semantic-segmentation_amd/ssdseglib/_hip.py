@@ -97,6 +97,7 @@ _SIGNATURES = {
     "ssdseg_conv3x3_fwd_saved": [_vp, _VP, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "ssdseg_conv3x3_bwd_weight_saved": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i],
     "ssdseg_conv3x3_bwd_data": [_vp, _GP, _vp, _vp, _i, _i, _i, _i, _i, _i, _i],
+    "ssdseg_conv3x3_bwd_data_bn": [_vp, _VP, _GP, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "ssdseg_conv3x3_bwd_weight": [_vp, _VP, _i, _GP, _vp, _i, _i, _i, _i, _i],
     "ssdseg_bn_finalize": [_vp, _vp, _i, _i, _d, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i],
     "ssdseg_channel_stats_parts": [_i, _i, _ip],
@@ -111,6 +112,8 @@ _SIGNATURES = {
     "ssdseg_bilinear_bwd": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i],
     "ssdseg_mask_head_fwd": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, C.POINTER(_f), _vp, _vp],
     "ssdseg_mask_head_bwd": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, C.POINTER(_f), _f, _vp],
+    "ssdseg_mask_head_fwd_dice": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, C.POINTER(_f), _i, _vp, _vp, _vp],
+    "ssdseg_mask_head_bwd_dice": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _f, _vp],
     "ssdseg_head_gather": [_vp, _VP, _vp, _i, _i, _i, _i, _i, _i],
     "ssdseg_softmax_rows": [_vp, _VP, _vp, _i, _i],
     "ssdseg_det_loss": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],

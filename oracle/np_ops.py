@@ -298,6 +298,20 @@ def dice_loss(y_true, p, class_weights, squared=False):
     return ((1.0 - (2.0 * inter + eps) / (total + eps)) * w).sum(axis=-1)
 
 
+def dice_loss_grad(y_true, p, class_weights, squared=False):
+    """losses.dice / dice_square (losses.py:204-216, 250-262) -> loss (B,), dL_b/dp: with I = sum y p and T = sum (y + p)
+    [sum (y^2 + p^2)] over the pixels of an image, d/dp [1 - (2 I + eps) / (T + eps)] = -2 y / (T + eps) + (2 I + eps) / (T + eps)^2 * dT/dp,
+    dT/dp = 1 [2 p]."""
+    w = np.asarray(class_weights, p.dtype)
+    inter = (y_true * p).sum(axis=(1, 2), keepdims=True)
+    total = (y_true ** 2 + p ** 2).sum(axis=(1, 2), keepdims=True) if squared else (y_true + p).sum(axis=(1, 2), keepdims=True)
+    eps = np.asarray(EPS, p.dtype)
+    loss = ((1.0 - (2.0 * inter + eps) / (total + eps)) * w).sum(axis=(1, 2, 3))
+    dt = 2.0 * p if squared else np.ones_like(p)
+    dp = w * (-2.0 * y_true / (total + eps) + (2.0 * inter + eps) / (total + eps) ** 2 * dt)
+    return loss, dp
+
+
 def localization_loss(y_true, y_pred):
     """losses.localization_loss (losses.py:21-49) -> loss (B,), dL_b/dy_pred."""
     dt = y_pred.dtype

@@ -49,7 +49,8 @@ def make_targets(rng, boxes, batch):
     return enc, gts, {'output-mask': np.eye(4, dtype=np.float32)[mask], 'output-labels': labels, 'output-boxes': offsets}
 
 
-def test_full_train_step_parity(ctx, rng):
+@pytest.mark.parametrize("mask_loss", ["cross_entropy", "dice", "dice_square"])
+def test_full_train_step_parity(ctx, rng, mask_loss):
     import ssdseglib
     from ssdseglib import _engine as E
     batch = 3       # (2 would make the 1x1-map BatchNorms see two samples, whose input gradient is identically zero)
@@ -69,7 +70,7 @@ def test_full_train_step_parity(ctx, rng):
     assert targets['output-labels'][..., 1:].sum() > 0, "test needs at least one positive anchor"
 
     model.compile(optimizer=ssdseglib.optimizers.Adam(learning_rate=1e-4),
-                  loss={'output-mask': ssdseglib.losses.cross_entropy(classes_weights=CW), 'output-labels': ssdseglib.losses.confidence_loss,
+                  loss={'output-mask': getattr(ssdseglib.losses, mask_loss)(classes_weights=CW), 'output-labels': ssdseglib.losses.confidence_loss,
                         'output-boxes': ssdseglib.losses.localization_loss},
                   loss_weights={'output-mask': 1.0, 'output-labels': 1.0, 'output-boxes': 1.0})
     E.Engine.keep_mask_probabilities = True
@@ -82,7 +83,10 @@ def test_full_train_step_parity(ctx, rng):
 
     ref = NpModel(model, dtype=np.float64)
     p_mask, p_labels, p_boxes = ref.forward(x, training=True)
-    l_mask, dmask = O.cross_entropy_loss(targets['output-mask'].astype(np.float64), p_mask, np.asarray(CW, np.float64))
+    if mask_loss == "cross_entropy":
+        l_mask, dmask = O.cross_entropy_loss(targets['output-mask'].astype(np.float64), p_mask, np.asarray(CW, np.float64))
+    else:       # the reference's dice losses as the training loss of the mask head (losses.py:175-264)
+        l_mask, dmask = O.dice_loss_grad(targets['output-mask'].astype(np.float64), p_mask, np.asarray(CW, np.float64), squared=mask_loss == "dice_square")
     l_conf, dconf, _ = O.confidence_loss(targets['output-labels'].astype(np.float64), p_labels)
     l_loc, dloc = O.localization_loss(targets['output-boxes'].astype(np.float64), p_boxes)
 

@@ -44,7 +44,7 @@ def gview_inputs(rng, shape, act):
                                             (1, 8, 32, 12, 16),     # cin not a multiple of 8: the implicit-GEMM forward, halo-tile backward
                                             (2, 6, 64, 80, 72),     # even h, w a multiple of 32: the Winograd weight gradient ("wino"), partial 64-channel patches, 3 splits
                                             (3, 2, 32, 64, 64),     # one tile row per image: every step crosses an image border of the padded copy
-                                            (5, 4, 32, 130, 70),    # Winograd weight gradient: 6 patches x 10 steps = 2 full chunks of 4 + a 2-step tail dealt to 3 blocks, each working on two patches in turn
+                                            (5, 4, 32, 132, 72),    # Winograd weight gradient: 6 patches x 10 steps = 2 full chunks of 4 + a 2-step tail dealt to 3 blocks, each working on two patches in turn
                                             (9, 2, 32, 72, 136)])   # ... 9 steps: a 1-step tail, one tail block walks four patches, the other two
 # kernel family: "narrow" = cout <= 8 as tap-expanded pointwise GEMMs (default for those shapes); "tile" = the halo-tile kernels
 # (conv3_tile.h); "wino" = the Winograd F(2x2, 3x3) kernels forced at every size (conv3_wino.h, default for the large layers: same
@@ -87,6 +87,25 @@ def test_conv3x3_fwd_bwd(ctx, rng, monkeypatch, n, h, w, cin, cout, family):
     ddx.upload(base)
     ctx.call("ssdseg_conv3x3_bwd_data", H.gview(*bufs, act=O.ACT_RELU6), dw_, ddx, cin, n, h, w, cin, cout, 1)
     assert rel_err(ddx.download(), dx_ref + base) < 2e-5
+    # input gradient + the BatchNorm backward of the layer feeding the conv (x is that BN's raw input): in the GEMM epilogue for the
+    # narrow form, conv + separate reduction otherwise -- the same numbers either way
+    mean = x.mean(axis=(0, 1, 2), dtype=np.float64).astype(np.float32)
+    invstd = (1.0 / np.sqrt(x.var(axis=(0, 1, 2), dtype=np.float64) + 1e-3)).astype(np.float32)
+    outs = [ctx.empty(cin) for _ in range(4)]
+    ddx.upload(base)
+    ctx.call("ssdseg_conv3x3_bwd_data_bn", H.view(dx_, dsc, dsh, act), H.gview(*bufs, act=O.ACT_RELU6), dw_, ddx, cin, n, h, w, cin, cout,
+             ctx.array(mean), ctx.array(invstd), *outs)
+    assert rel_err(ddx.download(), dx_ref) < 2e-5
+    cnt = n * h * w
+    mg = dx_ref * O.act_mask(x.astype(np.float64) * sc + sh, act)
+    xhat = (x.astype(np.float64) - mean) * invstd
+    dbeta, dgamma = mg.sum(axis=(0, 1, 2)), (mg * xhat).sum(axis=(0, 1, 2))
+    tol = 1e-4 * max(np.abs(dgamma).max(), np.abs(dbeta).max(), 1e-6)
+    assert np.abs(outs[0].download() - dgamma).max() < tol and np.abs(outs[1].download() - dbeta).max() < tol
+    k1_ref = -sc.astype(np.float64) * dgamma * invstd / cnt
+    k0_ref = sc.astype(np.float64) * (dgamma * invstd * mean - dbeta) / cnt
+    assert np.abs(outs[2].download() - k1_ref).max() < 1e-4 * max(np.abs(k1_ref).max(), 1e-9)
+    assert np.abs(outs[3].download() - k0_ref).max() < 1e-4 * max(np.abs(k0_ref).max(), 1e-9)
     # the engine's form: the BatchNorm gradient view materialised once, then the identity view (the halo-tile kernel's input),
     # written into a channel slice of a wider (concat) gradient buffer, overwrite and accumulate
     dmat = ctx.array(dy)
@@ -201,6 +220,39 @@ def test_mask_head(ctx, rng, monkeypatch, n, h, w):
     monkeypatch.setenv("SSDSEG_MASK_BWD", "gather")
     ctx.call("ssdseg_mask_head_bwd", dl, n, h, w, c, f, f, dy, cwh, 0.5, g)
     np.testing.assert_array_equal(g.download(), tile)
+
+
+@pytest.mark.parametrize("squared", [0, 1])
+@pytest.mark.parametrize("n,h,w", [(2, 6, 8), (3, 30, 40)])
+def test_mask_head_dice(ctx, rng, monkeypatch, n, h, w, squared):
+    """the mask head trained with the reference's dice / dice_square losses (losses.py:175-264): loss and d loss / d logits vs the
+    oracle (bilinear x4 -> softmax -> dice), tile and gather backward kernels bit-identical"""
+    c, f = 4, 4
+    logits = rng.normal(0, 2, (n, h, w, c)).astype(np.float32)
+    cls = rng.integers(0, c, (n, h * f, w * f))
+    y = np.eye(c, dtype=np.float32)[cls]
+    cw = np.array([0.05, 0.575, 0.135, 0.24], np.float32)
+    p_ref = O.softmax(O.bilinear_fwd(logits.astype(np.float64), f, f))
+    loss_ref, dp = O.dice_loss_grad(y.astype(np.float64), p_ref, cw.astype(np.float64), squared=bool(squared))
+    assert np.allclose(loss_ref, O.dice_loss(y.astype(np.float64), p_ref, cw.astype(np.float64), squared=bool(squared)), rtol=1e-12)
+    dlogits_ref = O.bilinear_bwd(O.softmax_bwd(p_ref, dp * 0.5), f, f)
+    cwh = (C.c_float * 4)(*cw)
+    dl, dy = ctx.array(logits), ctx.array(y)
+    prob, loss, coef = ctx.empty(y.shape), ctx.empty(n), ctx.empty((n, 8))
+    ctx.call("ssdseg_mask_head_fwd_dice", dl, n, h, w, c, f, f, dy, cwh, squared, prob, loss, coef)
+    assert np.abs(prob.download() - p_ref).max() < 2e-6
+    assert rel_err(loss.download(), loss_ref) < 1e-5
+    g = ctx.empty(logits.shape)
+    ctx.call("ssdseg_mask_head_bwd_dice", dl, n, h, w, c, f, f, dy, coef, squared, 0.5, g)
+    assert rel_err(g.download(), dlogits_ref) < 2e-5
+    tile = g.download()
+    monkeypatch.setenv("SSDSEG_MASK_BWD", "gather")
+    ctx.call("ssdseg_mask_head_bwd_dice", dl, n, h, w, c, f, f, dy, coef, squared, 0.5, g)
+    np.testing.assert_array_equal(g.download(), tile)
+    # the standalone loss function (ssdseglib.losses.dice(w)(y_true, y_pred)) agrees with the fused head
+    std = ctx.empty(n)
+    ctx.call("ssdseg_dice_loss", dy, prob, n, h * f * w * f, c, cwh, squared, std)
+    assert rel_err(std.download(), loss_ref) < 1e-5
 
 
 def test_head_gather_and_softmax(ctx, rng):
