@@ -264,7 +264,9 @@ void row_launch(long long m, int c, RowGeom* g, RowLaunch* l) {
     int by = 512 / bx;
     if (by > 64) by = 64;
     long long want = (m + (long long)by * 8 - 1) / ((long long)by * 8);  // >= 8 rows per thread
-    int gx = (int)(want < MAX_PARTS ? want : MAX_PARTS);
+    const char* pe = getenv("SSDSEG_BN_PARTS");       // (A/B runs) cap of partial rows of the streaming reductions
+    const int maxp = pe != nullptr && atoi(pe) >= 64 && atoi(pe) <= MAX_PARTS ? atoi(pe) : MAX_PARTS;
+    int gx = (int)(want < maxp ? want : maxp);
     if (gx < 1) gx = 1;
     l->block = dim3(bx, by, 1);
     l->grid = dim3(gx, cdiv(g->cv, bx), 1);

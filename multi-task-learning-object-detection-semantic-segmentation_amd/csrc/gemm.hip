@@ -930,8 +930,11 @@ int pw_tile_launch(ssdseg_ctx* ctx, PwTArgs a, int nparts_y, double view_bytes) 
     const int gx = cdiv(a.nout, a.ncols);
     const int bm = big ? 256 : 128;
     const int mtiles = cdiv(a.M, bm);
-    int gy = nparts_y > 0 ? nparts_y : (mtiles < 1024 ? mtiles : 1024);
+    const char* pe = getenv("SSDSEG_PWT_PARTS");       // (A/B runs) blocks of a launch without a caller-sized statistics table
+    const int cap = (pe != nullptr && atoi(pe) >= 64 ? atoi(pe) : 1024 * gx) / gx;
+    int gy = nparts_y > 0 ? nparts_y : (mtiles < cap ? mtiles : cap);
     if (gy > mtiles && nparts_y == 0) gy = mtiles;
+    if (gy < 1) gy = 1;
     a.a_bytes = (unsigned)((((long long)a.M - 1) * a.lda + a.cred) * 4);
     a.wt_bytes = (unsigned)((long long)a.nout * a.cred * 4);
     const dim3 grid(gx, gy, 1);
@@ -972,7 +975,8 @@ bool wres_enabled() { return wres_mode() != 0; }
 int rowA_grid_y(int rows, int cols) {
     const int wn = rowA_wn(rows, cols);
     const int ntiles = cdiv(cols, 32 * wn), mtiles = cdiv(rows, BM);
-    int gy = 2048 / ntiles;
+    const char* pe = getenv("SSDSEG_ROWA_PARTS");      // (A/B runs) cap of row-tile slots x column tiles
+    int gy = (pe != nullptr && atoi(pe) >= 64 ? atoi(pe) : 512) / ntiles;
     if (gy < 1) gy = 1;
     return mtiles < gy ? mtiles : gy;
 }
@@ -1864,7 +1868,9 @@ static int pwconv_bwd_data_bn(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, c
         t.out = dx; t.ldo = lddx;
         t.M = m; t.cred = n; t.nout = k;
         const int mt = cdiv(m, m >= 65536 ? 256 : 128);
-        const int gy = mt < 1024 ? mt : 1024;
+        const char* pe = getenv("SSDSEG_PWT_PARTS");
+        const int capb = pe != nullptr && atoi(pe) >= 64 ? atoi(pe) : 1024;
+        const int gy = mt < capb ? mt : capb;
         void* ws;
         rc = ssdseg_workspace(ctx, (size_t)gy * 2 * k * sizeof(float), &ws);
         if (rc) return rc;

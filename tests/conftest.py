@@ -26,10 +26,14 @@ KERNEL_FAMILIES = {
     # the row-naming weight-gradient kernel (pw_wgrad.h) and the two-rows-ahead depthwise forward are on in "default",
     # "resident-fused" and "tile", off in the others
     "tile": {"SSDSEG_PW_TILE": "1", "SSDSEG_OCC_ROWS": "0"},
+    # the tile GEMM's column-tile rule for layers below 65,536 rows (64 / 32 columns by shape in "tile"): every such layer on
+    # 32-column tiles, and on one tile of <= 160 columns (the rule before the short-M table)
+    "tile-32": {"SSDSEG_PW_TILE": "1", "SSDSEG_PWT_SMALL": "32"},
+    "tile-wide": {"SSDSEG_PW_TILE": "1", "SSDSEG_PWT_SMALL": "0"},
 }
 _FAMILY_VARS = ("SSDSEG_NO_WRES", "SSDSEG_WRES_FORCE", "SSDSEG_PW_FUSED", "SSDSEG_DW_FWD", "SSDSEG_DW_BWD", "SSDSEG_SPLITK", "SSDSEG_CONV3_WGRAD",
                 "SSDSEG_CONV3_NARROW", "SSDSEG_PW_TILE", "SSDSEG_CONV3_TILE", "SSDSEG_CONV3_WINOGRAD", "SSDSEG_OCC_ROWS", "SSDSEG_PW_WGRAD",
-                "SSDSEG_DW_FWD_DEPTH")
+                "SSDSEG_DW_FWD_DEPTH", "SSDSEG_PWT_SMALL")
 
 
 def pytest_configure(config):
