@@ -348,9 +348,24 @@ __global__ void __launch_bounds__(256, OCC ? rowa_min_waves(WN, MODE, NT) : 1) g
             }
             __syncthreads();
             if (eact) {
+                // Rows er, er + RPP, ... of this half, FOUR at a time: the global loads of a group (the raw input of the fused
+                // BatchNorm sums, residual, previous dx) are issued together and the group is then consumed in row order -- the
+                // summation order per thread is unchanged.  One row per trip left a single 16-byte load in flight per thread
+                // (8 KB per CU): the project-conv backward GEMMs of blocks 0-3 ran at 2.2-3.3 TB/s of real traffic.
+                // Only where the registers are there (<= 3 column tiles, the register-limited big-M instantiations): at 4-5 column
+                // tiles the extra float4s spill (block-2 project conv +11 %), and the short-M instantiations would lose a wave per SIMD.
+                constexpr int ITER = (64 + RPP - 1) / RPP;
+                constexpr int EU = (OCC && WN <= 3) ? 4 : 1;
+                if constexpr (EU == 1) {
+                // one row per trip, the raw input of the fused BatchNorm sums fetched one row AHEAD (two loads in flight per thread
+                // for four more registers)
+                float4 ynext = f4(0.f);
+                if (BNE && m0 + h * 64 + er < p.I) ynext = ld4(p.bn_y + (long long)(m0 + h * 64 + er) * p.ldby + ej);
                 for (int row = er; row < 64; row += RPP) {
                     const int m = m0 + h * 64 + row;
                     if (m >= p.I) break;
+                    const float4 yv = ynext;
+                    if (BNE && row + RPP < 64 && m + RPP < p.I) ynext = ld4(p.bn_y + (long long)(m + RPP) * p.ldby + ej);
                     float4 v = ld4(Cs + row * CS + ec4 * 4);
                     if (MODE == 1 && p.residual) {
                         const float4 r4 = ld4(p.residual + (long long)m * p.ldr + ej);
@@ -363,7 +378,6 @@ __global__ void __launch_bounds__(256, OCC ? rowa_min_waves(WN, MODE, NT) : 1) g
                     }
                     st4(o, v);
                     if (!BNE) continue;
-                    const float4 yv = ld4(p.bn_y + (long long)m * p.ldby + ej);
                     float4 mg;
                     mg.x = (fmaf(ebs.x, yv.x, ebt.x) > bnlo && fmaf(ebs.x, yv.x, ebt.x) < bnhi) ? v.x : 0.f;
                     mg.y = (fmaf(ebs.y, yv.y, ebt.y) > bnlo && fmaf(ebs.y, yv.y, ebt.y) < bnhi) ? v.y : 0.f;
@@ -372,6 +386,43 @@ __global__ void __launch_bounds__(256, OCC ? rowa_min_waves(WN, MODE, NT) : 1) g
                     esb.x += mg.x; esb.y += mg.y; esb.z += mg.z; esb.w += mg.w;
                     esg.x = fmaf(mg.x, (yv.x - ebm.x) * ebi.x, esg.x); esg.y = fmaf(mg.y, (yv.y - ebm.y) * ebi.y, esg.y);
                     esg.z = fmaf(mg.z, (yv.z - ebm.z) * ebi.z, esg.z); esg.w = fmaf(mg.w, (yv.w - ebm.w) * ebi.w, esg.w);
+                }
+                } else {
+#pragma unroll
+                for (int it0 = 0; it0 < ITER; it0 += EU) {
+                    float4 cv[EU], yv4[EU], rv4[EU], ov4[EU];
+                    bool rok[EU];
+#pragma unroll
+                    for (int u = 0; u < EU; ++u) {
+                        const int row = er + (it0 + u) * RPP;
+                        const int m = m0 + h * 64 + row;
+                        rok[u] = (it0 + u) < ITER && row < 64 && m < p.I;
+                        const long long mm = rok[u] ? m : 0;               // clamped address, value unused
+                        if (BNE) yv4[u] = ld4(p.bn_y + mm * p.ldby + ej);
+                        if (MODE == 1 && p.residual) rv4[u] = ld4(p.residual + mm * p.ldr + ej);
+                        if (MODE == 1 && p.accumulate) ov4[u] = ld4(p.out + mm * p.ldo + ej);
+                        cv[u] = ld4(Cs + (rok[u] ? row : 0) * CS + ec4 * 4);
+                    }
+#pragma unroll
+                    for (int u = 0; u < EU; ++u) {
+                        if (!rok[u]) continue;
+                        const int m = m0 + h * 64 + er + (it0 + u) * RPP;
+                        float4 v = cv[u];
+                        if (MODE == 1 && p.residual) { v.x += rv4[u].x; v.y += rv4[u].y; v.z += rv4[u].z; v.w += rv4[u].w; }
+                        if (MODE == 1 && p.accumulate) { v.x += ov4[u].x; v.y += ov4[u].y; v.z += ov4[u].z; v.w += ov4[u].w; }
+                        st4(p.out + (long long)m * p.ldo + ej, v);
+                        if (!BNE) continue;
+                        const float4 yv = yv4[u];
+                        float4 mg;
+                        mg.x = (fmaf(ebs.x, yv.x, ebt.x) > bnlo && fmaf(ebs.x, yv.x, ebt.x) < bnhi) ? v.x : 0.f;
+                        mg.y = (fmaf(ebs.y, yv.y, ebt.y) > bnlo && fmaf(ebs.y, yv.y, ebt.y) < bnhi) ? v.y : 0.f;
+                        mg.z = (fmaf(ebs.z, yv.z, ebt.z) > bnlo && fmaf(ebs.z, yv.z, ebt.z) < bnhi) ? v.z : 0.f;
+                        mg.w = (fmaf(ebs.w, yv.w, ebt.w) > bnlo && fmaf(ebs.w, yv.w, ebt.w) < bnhi) ? v.w : 0.f;
+                        esb.x += mg.x; esb.y += mg.y; esb.z += mg.z; esb.w += mg.w;
+                        esg.x = fmaf(mg.x, (yv.x - ebm.x) * ebi.x, esg.x); esg.y = fmaf(mg.y, (yv.y - ebm.y) * ebi.y, esg.y);
+                        esg.z = fmaf(mg.z, (yv.z - ebm.z) * ebi.z, esg.z); esg.w = fmaf(mg.w, (yv.w - ebm.w) * ebi.w, esg.w);
+                    }
+                }
                 }
             }
         }
@@ -831,7 +882,23 @@ int pick_wn(int n, long long row_blocks) {
     return best;
 }
 
-int rowA_wn(int rows, int cols) { return pick_wn(cols, cdiv(rows, BM)); }
+int rowA_wn(int rows, int cols);
+// Backward-data GEMMs with a tiny reduction (<= 48 channels: the project convs of blocks 1-3, the decoder's backbone / logits convs)
+// are all epilogue: 128 x 144 outputs per 128 x 24 inputs.  At 4-5 column tiles the float4 epilogue walks 11 rows per thread with
+// one load in flight; at <= 3 it takes four rows at a time (gemm_rowA_kernel, EU) -- two 96- / 72-column tiles beat one of 144 / 160
+// although the narrow operand is read twice (block-2 project conv 379 -> 277 us).  Only for the register-limited big-M instantiations.
+int rowA_wn_bwd(int rows, int cols, int red) {
+    const int wn = rowA_wn(rows, cols);
+    const char* e = getenv("SSDSEG_ROWA_BWD_WN");         // (A/B runs) "0": no cap
+    const int cap = e != nullptr ? atoi(e) : 3;
+    return (cap >= 1 && rows >= occ_rows() && red <= 48 && wn > cap) ? cap : wn;
+}
+int rowA_wn(int rows, int cols) {
+    const int wn = pick_wn(cols, cdiv(rows, BM));
+    const char* e = getenv("SSDSEG_ROWA_WN_MAX");        // (A/B runs) widest column tile, in 32-column units
+    if (e != nullptr && atoi(e) >= 1 && wn > atoi(e)) return atoi(e);
+    return wn;
+}
 
 #include "gemm_wres.h"
 #include "conv3_wgrad.h"
@@ -972,8 +1039,9 @@ bool wres_enabled() { return wres_mode() != 0; }
 
 // row-tile slots per column tile: enough blocks to fill the chip (~8 per CU), few enough that the BN partial
 // table stays short
-int rowA_grid_y(int rows, int cols) {
-    const int wn = rowA_wn(rows, cols);
+int rowA_grid_y_wn(int rows, int cols, int wn);
+int rowA_grid_y(int rows, int cols) { return rowA_grid_y_wn(rows, cols, rowA_wn(rows, cols)); }
+int rowA_grid_y_wn(int rows, int cols, int wn) {
     const int ntiles = cdiv(cols, 32 * wn), mtiles = cdiv(rows, BM);
     const char* pe = getenv("SSDSEG_ROWA_PARTS");      // (A/B runs) cap of row-tile slots x column tiles
     int gy = (pe != nullptr && atoi(pe) >= 64 ? atoi(pe) : 512) / ntiles;
@@ -1041,7 +1109,7 @@ bool splitk_enabled() { return getenv("SSDSEG_SPLITK") != nullptr && getenv("SSD
 template <int MODE, int LD>
 int launch_rowA(ssdseg_ctx* ctx, const RowAArgs& a0, const float* wt_pre = nullptr) {
     RowAArgs a = a0;
-    int wn = rowA_wn(a.I, a.J);
+    int wn = (MODE == 1 && LD == 0) ? rowA_wn_bwd(a.I, a.J, a.R) : rowA_wn(a.I, a.J);
     const int nparts = rowA_grid_y(a.I, a.J);   // BN-statistics partial rows the caller allocated: fixed by (I, J) alone
     if (LD == 0 && pw_tile_mode() != 0 && pw_tile_takes(a.I, a.lda, a.R, a.J) && !(MODE == 0 && (a.residual != nullptr || a.accumulate != 0)) && (pw_tile_mode() == 1 || pw_tile_default(MODE, a.I, a.R, a.J, false, a.accumulate != 0 || a.residual != nullptr))) {
         PwTArgs t{};
@@ -1084,7 +1152,7 @@ int launch_rowA(ssdseg_ctx* ctx, const RowAArgs& a0, const float* wt_pre = nullp
     // re-reads the whole (g, y) operand from the fabric (measured 5 TB/s of L2-level reads for 1.4 TB/s algorithmic).  One
     // column tile spanning all outputs reads it once; with >= 256 row tiles there is still a block per CU (109 -> 88 us).
     // Not for the 15x20 stage (75 row tiles: 2x slower) and no gain for the forward (single-tensor operand).
-    int grid_y = nparts;
+    int grid_y = (MODE == 1 && LD == 0) ? rowA_grid_y_wn(a.I, a.J, wn) : nparts;   // (no statistics table in backward-data: free choice)
     if (MODE == 1 && LD == 0 && splits == 1 && a.cs != nullptr && a.R >= 256) {
         const int wide = cdiv(a.J, 32), mtiles = cdiv(a.I, BM);
         if (wide > wn && wide <= 3 && mtiles >= 256 && a.I < ROWA_OCC_ROWS) { wn = wide; grid_y = mtiles < 2048 ? mtiles : 2048; }
@@ -1886,8 +1954,8 @@ static int pwconv_bwd_data_bn(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, c
     a.b = w; a.ldb = n;
     a.out = dx; a.ldo = lddx;
     a.I = m; a.R = n; a.J = k;
-    const int wn = rowA_wn(m, k);
-    const int nparts = rowA_grid_y(m, k);
+    const int wn = rowA_wn_bwd(m, k, n);
+    const int nparts = rowA_grid_y_wn(m, k, wn);
     void* ws;
     rc = ssdseg_workspace(ctx, (size_t)nparts * 2 * k * sizeof(float), &ws);
     if (rc) return rc;
