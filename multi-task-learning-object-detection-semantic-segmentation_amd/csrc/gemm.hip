@@ -1452,14 +1452,15 @@ __global__ void conv3n_pack_w_kernel(const float* __restrict__ w, float* __restr
 __global__ void __launch_bounds__(256) conv3n_tapsum_kernel(const float* __restrict__ z, float* __restrict__ y, int n, int h, int w, int cv,
                                                             float* __restrict__ stats) {
     __shared__ float4 red[2][256];
-    const long long total = (long long)n * h * w * cv;
+    // (32-bit index arithmetic: the launcher guarantees n*h*w*9*cv < 2^31 -- 64-bit divisions cost more than the kernel's traffic)
+    const int total = n * h * w * cv;
     const int ldz = 9 * cv * 4;
     float4 ssum = f4(0.f), ssq = f4(0.f);
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int c4 = (int)(i % cv);
-        long long r = i / cv;
-        const int x = (int)(r % w); r /= w;
-        const int yy = (int)(r % h);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int c4 = i % cv;
+        int r = i / cv;
+        const int x = r % w; r /= w;
+        const int yy = r % h;
         const long long img = r / h;
         float4 acc = f4(0.f);
 #pragma unroll
@@ -1467,7 +1468,7 @@ __global__ void __launch_bounds__(256) conv3n_tapsum_kernel(const float* __restr
             const int sy = yy + tap / 3 - 1, sx = x + tap % 3 - 1;
             if (sy >= 0 && sy < h && sx >= 0 && sx < w) add4(acc, ld4(z + ((img * h + sy) * w + sx) * ldz + (tap * cv + c4) * 4));
         }
-        st4(y + i * 4, acc);
+        st4(y + (long long)i * 4, acc);
         add4(ssum, acc);
         ssq.x = fmaf(acc.x, acc.x, ssq.x); ssq.y = fmaf(acc.y, acc.y, ssq.y); ssq.z = fmaf(acc.z, acc.z, ssq.z); ssq.w = fmaf(acc.w, acc.w, ssq.w);
     }
@@ -1489,26 +1490,27 @@ __global__ void __launch_bounds__(256) conv3n_shift_kernel(const float* __restri
                                                            const float* __restrict__ gt, const float* __restrict__ gk1,
                                                            const float* __restrict__ gk0, int gact, float* __restrict__ dz, int n, int h, int w,
                                                            int cv) {
-    const long long total = (long long)n * h * w * 9 * cv;
+    const int total = n * h * w * 9 * cv;      // < 2^31 (launcher)
     const bool aff = gs != nullptr;
     const float* yp = aff ? yv : g;
     const int act = aff ? gact : SSDSEG_ACT_NONE;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int c4 = (int)(i % cv);
-        long long r = i / cv;
-        const int tap = (int)(r % 9); r /= 9;
-        const int x = (int)(r % w); r /= w;
-        const int yy = (int)(r % h);
+    float4 s = f4(1.f), t = f4(0.f), k1 = f4(0.f), k0 = f4(0.f);
+    const int cfix = threadIdx.x % cv;           // 256 % cv == 0 and the grid stride is a multiple of 256: a thread keeps its channel vector
+    if (aff) { s = ld4(gs + cfix * 4); t = ld4(gt + cfix * 4); k1 = ld4(gk1 + cfix * 4); k0 = ld4(gk0 + cfix * 4); }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int c4 = cfix;
+        int r = i / cv;
+        const int tap = r % 9; r /= 9;
+        const int x = r % w; r /= w;
+        const int yy = r % h;
         const long long img = r / h;
         const int sy = yy - (tap / 3 - 1), sx = x - (tap % 3 - 1);
         float4 v = f4(0.f);
         if (sy >= 0 && sy < h && sx >= 0 && sx < w) {
             const long long o = (((img * h + sy) * w + sx) * cv + c4) * 4;
-            float4 s = f4(1.f), t = f4(0.f), k1 = f4(0.f), k0 = f4(0.f);
-            if (aff) { s = ld4(gs + c4 * 4); t = ld4(gt + c4 * 4); k1 = ld4(gk1 + c4 * 4); k0 = ld4(gk0 + c4 * 4); }
             v = gview_apply4(ld4(g + o), ld4(yp + o), s, t, k1, k0, act);
         }
-        st4(dz + i * 4, v);
+        st4(dz + (long long)i * 4, v);
     }
 }
 
@@ -2164,6 +2166,7 @@ int ssdseg_conv3x3_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const fl
         int nparts = 0;
         ssdseg_conv3x3_parts(n, h, wdt, cin, cout, &nparts);
         const int cv = cout / 4;
+        SSDSEG_ARG((long long)m * cv < (1LL << 31), 6);   // 32-bit element indices in conv3n_tapsum_kernel
         int blocks = stats != nullptr ? nparts : (int)((m * cv + 255) / 256 < 4096 ? (m * cv + 255) / 256 : 4096);
         SSDSEG_LAUNCH(ctx, 4.0 * m * (nc + cout), 0.0, conv3n_tapsum_kernel, dim3(blocks), dim3(256), 0, (const float*)z, y, n, h, wdt, cv, stats);
         SSDSEG_LAUNCH_CHECK();
@@ -2282,6 +2285,7 @@ int ssdseg_conv3x3_bwd_data_bn(ssdseg_ctx* ctx, const ssdseg_view* in, const ssd
         SSDSEG_LAUNCH(ctx, 8.0 * 9 * cin * cout, 0.0, conv3n_pack_w_kernel, dim3(cdiv(9 * cin * cout, 256)), dim3(256), 0, w, w2, cin, cout, 0);
         SSDSEG_LAUNCH_CHECK();
         const long long tot = m * 9 * cv;
+        SSDSEG_ARG(tot < (1LL << 31), 6);       // 32-bit element indices in conv3n_shift_kernel
         SSDSEG_LAUNCH(ctx, 4.0 * m * (nc + (dy->scale ? 2.0 : 1.0) * cout), 0.0, conv3n_shift_kernel, dim3((unsigned)((tot + 255) / 256 < 8192 ? (tot + 255) / 256 : 8192)),
                       dim3(256), 0, dy->g, dy->y, dy->scale, dy->shift, dy->k1, dy->k0, dy->act, dz, n, h, wdt, cv);
         SSDSEG_LAUNCH_CHECK();
@@ -2320,6 +2324,7 @@ int ssdseg_conv3x3_bwd_data(ssdseg_ctx* ctx, const ssdseg_gview* dy, const float
         SSDSEG_LAUNCH(ctx, 8.0 * 9 * cin * cout, 0.0, conv3n_pack_w_kernel, dim3(cdiv(9 * cin * cout, 256)), dim3(256), 0, w, w2, cin, cout, 0);
         SSDSEG_LAUNCH_CHECK();
         const long long tot = m * 9 * cv;
+        SSDSEG_ARG(tot < (1LL << 31), 6);       // 32-bit element indices in conv3n_shift_kernel
         SSDSEG_LAUNCH(ctx, 4.0 * m * (nc + (dy->scale ? 2.0 : 1.0) * cout), 0.0, conv3n_shift_kernel, dim3((unsigned)((tot + 255) / 256 < 8192 ? (tot + 255) / 256 : 8192)),
                       dim3(256), 0, dy->g, dy->y, dy->scale, dy->shift, dy->k1, dy->k0, dy->act, dz, n, h, wdt, cv);
         SSDSEG_LAUNCH_CHECK();
@@ -2380,6 +2385,7 @@ int ssdseg_conv3x3_bwd_weight(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, c
         float* dw2 = (float*)ws;
         float* dz = (float*)((char*)ws + wb);
         const long long tot = m * 9 * cv;
+        SSDSEG_ARG(tot < (1LL << 31), 6);       // 32-bit element indices in conv3n_shift_kernel
         SSDSEG_LAUNCH(ctx, 4.0 * m * (nc + (dy->scale ? 2.0 : 1.0) * cout), 0.0, conv3n_shift_kernel, dim3((unsigned)((tot + 255) / 256 < 8192 ? (tot + 255) / 256 : 8192)),
                       dim3(256), 0, dy->g, dy->y, dy->scale, dy->shift, dy->k1, dy->k0, dy->act, dz, n, h, wdt, cv);
         SSDSEG_LAUNCH_CHECK();
