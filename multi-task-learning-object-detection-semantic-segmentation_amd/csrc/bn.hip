@@ -15,24 +15,26 @@ constexpr int RTHREADS = 256;   // small blocks: they have to find room next to 
 
 // Sums part[p][v][ch] over p for v < NV: RP lanes along p per channel, 4 independent fp64 chains per lane, then a fixed-
 // order fold (deterministic).  Result valid for threadIdx.y == 0.  red: NV * RP * (RC + 1) doubles of LDS.
-template <int NV, int RC>
+// CH: independent chains (= loads in flight) per lane and value: 4 for the two-value BatchNorm tables, 8 for the column sums of the
+// weight-gradient slabs (tall tables read once: latency is all there is)
+template <int NV, int RC, int CH = 4>
 __device__ __forceinline__ void reduce_parts(const float* __restrict__ part, int nparts, int c, int ch, double (&tot)[NV], double* red) {
     constexpr int RP = RTHREADS / RC;
-    double acc[NV][4];
+    double acc[NV][CH];
 #pragma unroll
     for (int v = 0; v < NV; ++v)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc[v][u] = 0.0;
+        for (int u = 0; u < CH; ++u) acc[v][u] = 0.0;
     if (ch < c) {
         int p = threadIdx.y;
-        for (; p + 3 * RP < nparts; p += 4 * RP) {
-            float f[NV][4];
+        for (; p + (CH - 1) * RP < nparts; p += CH * RP) {
+            float f[NV][CH];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < CH; ++u)
 #pragma unroll
                 for (int v = 0; v < NV; ++v) f[v][u] = part[((long long)(p + u * RP) * NV + v) * c + ch];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < CH; ++u)
 #pragma unroll
                 for (int v = 0; v < NV; ++v) acc[v][u] += (double)f[v][u];
         }
@@ -42,7 +44,15 @@ __device__ __forceinline__ void reduce_parts(const float* __restrict__ part, int
         }
     }
 #pragma unroll
-    for (int v = 0; v < NV; ++v) red[(v * RP + threadIdx.y) * (RC + 1) + threadIdx.x] = (acc[v][0] + acc[v][1]) + (acc[v][2] + acc[v][3]);
+    for (int v = 0; v < NV; ++v) {
+        double s = 0.0;
+        if (CH == 4) s = (acc[v][0] + acc[v][1]) + (acc[v][2] + acc[v][3]);
+        else {
+#pragma unroll
+            for (int u = 0; u < CH; u += 4) s += (acc[v][u] + acc[v][u + 1]) + (acc[v][u + 2] + acc[v][u + 3]);
+        }
+        red[(v * RP + threadIdx.y) * (RC + 1) + threadIdx.x] = s;
+    }
     __syncthreads();
     // fold RP -> 8 lanes in parallel, then serially (fixed order either way)
     for (int half = RP / 2; half >= 8; half >>= 1) {
@@ -199,7 +209,7 @@ __global__ void __launch_bounds__(RTHREADS) colsum_kernel(const float* __restric
     __shared__ double red[(RTHREADS / RC) * (RC + 1)];
     const int l = blockIdx.x * RC + threadIdx.x;
     double tot[1] = {0.0};
-    reduce_parts<1, RC>(part, nparts, len, l, tot, red);
+    reduce_parts<1, RC, 8>(part, nparts, len, l, tot, red);
     if (threadIdx.y == 0 && l < len) out[l] = (float)tot[0];
 }
 
