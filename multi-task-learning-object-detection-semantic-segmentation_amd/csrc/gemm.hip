@@ -916,18 +916,19 @@ int pw_tile_mode() {
     return e == nullptr ? 2 : (e[0] == '0' ? 0 : 1);
 }
 
-template <int WAVES, int WN, int MODE>
+template <int WAVES, int WN, int MODE, int WNW = 1>
 int pwt_launch_inst(ssdseg_ctx* ctx, const PwTArgs& a, dim3 grid, double cost_bytes, double cost_flops) {
-    const size_t lds = pwt_lds_floats(WAVES, WN, a.cred) * sizeof(float);
+    const size_t lds = pwt_lds_floats(32 * WAVES / WNW, 32 * WN * WNW, a.cred) * sizeof(float);
     static size_t configured = 0;
     if (lds > configured) {
-        SSDSEG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_tile_kernel<WAVES, WN, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SSDSEG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_tile_kernel<WAVES, WN, MODE, WNW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = lds;
     }
     char kbuf[64];
-    snprintf(kbuf, sizeof(kbuf), "pw_tile_kernel<%d, %d, %d>", WAVES, WN, MODE);
+    if (WNW == 1) snprintf(kbuf, sizeof(kbuf), "pw_tile_kernel<%d, %d, %d>", WAVES, WN, MODE);
+    else snprintf(kbuf, sizeof(kbuf), "pw_tile_kernel<%d, %d, %d, %d>", WAVES, WN, MODE, WNW);
     const char* kname = ctx->timing ? ssdseg_intern(kbuf) : "";
-    SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (pw_tile_kernel<WAVES, WN, MODE>), grid, dim3(64 * WAVES), lds, a);
+    SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, (pw_tile_kernel<WAVES, WN, MODE, WNW>), grid, dim3(64 * WAVES), lds, a);
     SSDSEG_LAUNCH_CHECK();
     return 0;
 }
@@ -994,8 +995,13 @@ int pw_tile_launch(ssdseg_ctx* ctx, PwTArgs a, int nparts_y, double view_bytes) 
         a.ncols = (cdiv(a.nout, nt2) + 3) / 4 * 4;
         wn = cdiv(a.ncols, 32);
     }
+    // input gradient with 161 .. 256 output columns at >= 65,536 rows (the decoder sepconv): a 4 x 2 wave grid over a 128-row block
+    // that spans ALL columns -- the two-tensor operand is streamed once, not once per 128-column tile (SSDSEG_PWT_GRID=0: off)
+    const char* ge = getenv("SSDSEG_PWT_GRID");
+    const bool grid42 = MODE == 1 && big && a.nout > 160 && a.nout <= 256 && !(ge != nullptr && ge[0] == '0');
+    if (grid42) { a.ncols = (a.nout + 3) / 4 * 4; wn = cdiv(a.ncols, 64); }
     const int gx = cdiv(a.nout, a.ncols);
-    const int bm = big ? 256 : 128;
+    const int bm = grid42 ? 128 : (big ? 256 : 128);
     const int mtiles = cdiv(a.M, bm);
     const char* pe = getenv("SSDSEG_PWT_PARTS");       // (A/B runs) blocks of a launch without a caller-sized statistics table
     const int cap = (pe != nullptr && atoi(pe) >= 64 ? atoi(pe) : 1024 * gx) / gx;
@@ -1009,6 +1015,12 @@ int pw_tile_launch(ssdseg_ctx* ctx, PwTArgs a, int nparts_y, double view_bytes) 
     const double cost_flops = 2.0 * a.M * a.cred * a.nout;
     ctx->timing_view_bytes = view_bytes;
 #define PWT_CASE(W, N) return pwt_launch_inst<W, N, MODE>(ctx, a, grid, cost_bytes, cost_flops)
+    if constexpr (MODE == 1) {
+        if (grid42) {
+            if (wn <= 3) return pwt_launch_inst<8, 3, MODE, 2>(ctx, a, grid, cost_bytes, cost_flops);
+            return pwt_launch_inst<8, 4, MODE, 2>(ctx, a, grid, cost_bytes, cost_flops);
+        }
+    }
     if (big) {
         if (wn <= 2) PWT_CASE(8, 2);
         if (wn <= 4) PWT_CASE(8, 4);

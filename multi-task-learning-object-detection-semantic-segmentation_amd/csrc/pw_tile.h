@@ -69,12 +69,19 @@ __device__ __forceinline__ void lds_dma16(pwt_i32x4 rsrc, unsigned lds_byte_addr
                  : "=&s"(keep) : "s"(lds_byte_addr), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
 }
 
-constexpr size_t pwt_lds_floats(int waves, int wn, int cred) { return 2 * (size_t)(32 * waves + 32 * wn) * PWT_KC + 4 * (size_t)((cred + 31) / 32 * 32 + PWT_KC); }
+// (rows, cols): 32 * waves-along-M, 32 * WN * waves-along-N
+constexpr size_t pwt_lds_floats(int rows, int cols, int cred) { return 2 * (size_t)(rows + cols) * PWT_KC + 4 * (size_t)((cred + 31) / 32 * 32 + PWT_KC); }
 
-template <int WAVES, int WN, int MODE>
+// WNW: waves along the columns.  WNW = 1: every wave owns 32 rows of the block and all 32 * WN columns.  WNW = 2: the eight waves form a
+// 4 x 2 grid over a 128-row x (2 * 32 * WN)-column block tile, each wave 32 rows x 32 * WN columns -- for the input gradient of a
+// 256 -> 256 conv (the decoder sepconv) the block then spans ALL output columns with 64 accumulator registers per wave, and the
+// two-tensor gradient view is streamed ONCE instead of once per 128-column tile.
+template <int WAVES, int WN, int MODE, int WNW = 1>
 __global__ void __launch_bounds__(64 * WAVES, 2) pw_tile_kernel(PwTArgs p) {
     constexpr int T = 64 * WAVES;
-    constexpr int BM = 32 * WAVES, BN = 32 * WN;
+    constexpr int WM = WAVES / WNW;
+    static_assert(WM * WNW == WAVES, "wave grid");
+    constexpr int BM = 32 * WM, BN = 32 * WN * WNW;
     constexpr int A_F = BM * PWT_KC, B_F = BN * PWT_KC, BUF_F = A_F + B_F;
     constexpr int AQ = BM * 8 / T;                      // float4 slots of A per thread (4)
     constexpr int BSLOTS = BN * 8;
@@ -87,6 +94,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) pw_tile_kernel(PwTArgs p) {
     const int t = threadIdx.x;
     const int wave = t >> 6, lane = t & 63, li = lane & 31, hh = lane >> 5;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave % WM, wnw = wave / WM;          // this wave's 32 rows / its group of 32 * WN columns
     const int n0 = blockIdx.x * p.ncols;
     const int mtiles = (p.M + BM - 1) / BM;
     const int S = (p.cred + PWT_KC - 1) / PWT_KC;
@@ -131,7 +139,8 @@ __global__ void __launch_bounds__(64 * WAVES, 2) pw_tile_kernel(PwTArgs p) {
     int fo[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) fo[g] = li * PWT_KC + 4 * ((2 * g + hh) ^ ((li >> 1) & 7));
-    const int abase = wave * 32 * PWT_KC;
+    const int abase = wm * 32 * PWT_KC;
+    const int bbase = wnw * WN * 32 * PWT_KC;
 
     float ssum[WN], ssq[WN];          // MODE 0: BatchNorm statistics of this block's rows, carried across its row tiles
     float esb[WN], esg[WN];           // MODE 1 + bnpart: running sums of the fused BatchNorm backward
@@ -207,13 +216,13 @@ __global__ void __launch_bounds__(64 * WAVES, 2) pw_tile_kernel(PwTArgs p) {
         auto compute = [&](const float* buf) {
             float4 afr[2], bfr[2];
             afr[0] = ld4(buf + abase + fo[0]);
-            bfr[0] = ld4(buf + A_F + fo[0]);
+            bfr[0] = ld4(buf + A_F + bbase + fo[0]);
 #pragma unroll
             for (int u = 0; u < 4 * WN; ++u) {
                 const int g = u / WN, nt = u - g * WN;
                 if (u + 1 < 4 * WN) {
                     const int g1 = (u + 1) / WN, nt1 = (u + 1) - g1 * WN;
-                    bfr[(u + 1) & 1] = ld4(buf + A_F + nt1 * 32 * PWT_KC + fo[g1]);
+                    bfr[(u + 1) & 1] = ld4(buf + A_F + bbase + nt1 * 32 * PWT_KC + fo[g1]);
                     if (nt1 == 0) afr[g1 & 1] = ld4(buf + abase + fo[g1]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -241,13 +250,13 @@ __global__ void __launch_bounds__(64 * WAVES, 2) pw_tile_kernel(PwTArgs p) {
         // ---- epilogue: C/D layout col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * hh
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt) {
-            const int jl = nt * 32 + li, j = n0 + jl;
+            const int jl = (wnw * WN + nt) * 32 + li, j = n0 + jl;
             const bool jok = jl < p.ncols && j < p.nout;
             float bs = 0.f, bt = 0.f, bm = 0.f, bi = 0.f;
             if (bne && jok) { bs = p.bn_s[j]; bt = p.bn_t[j]; bm = p.bn_mean[j]; bi = p.bn_istd[j]; }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                const int m = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
                 if (jok && m < p.M) {
                     float v = acc[nt][e];
                     if (MODE == 0) {
@@ -276,15 +285,15 @@ __global__ void __launch_bounds__(64 * WAVES, 2) pw_tile_kernel(PwTArgs p) {
     // ---- per-block partial rows (fixed order): forward BatchNorm statistics / fused BatchNorm-backward sums
     float* s0 = MODE == 0 ? p.stats : p.bnpart;
     if (s0 != nullptr) {
-        float* red = smem;            // [WAVES][2][BN]
+        float* red = smem;            // [WM][2][BN]: a column is summed over the WM waves that hold rows of it, in wave order
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt) {
             float a = MODE == 0 ? ssum[nt] : esb[nt], b = MODE == 0 ? ssq[nt] : esg[nt];
             a += __shfl_xor(a, 32, 64);
             b += __shfl_xor(b, 32, 64);
             if (hh == 0) {
-                red[(wave * 2 + 0) * BN + nt * 32 + li] = a;
-                red[(wave * 2 + 1) * BN + nt * 32 + li] = b;
+                red[(wm * 2 + 0) * BN + (wnw * WN + nt) * 32 + li] = a;
+                red[(wm * 2 + 1) * BN + (wnw * WN + nt) * 32 + li] = b;
             }
         }
         __syncthreads();
@@ -294,7 +303,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) pw_tile_kernel(PwTArgs p) {
             if (jl < p.ncols && j < p.nout) {
                 float v = 0.f;
 #pragma unroll
-                for (int wv = 0; wv < WAVES; ++wv) v += red[(wv * 2 + which) * BN + jl];
+                for (int wv = 0; wv < WM; ++wv) v += red[(wv * 2 + which) * BN + jl];
                 s0[((long long)blockIdx.y * 2 + which) * p.nout + j] = v;
             }
         }
