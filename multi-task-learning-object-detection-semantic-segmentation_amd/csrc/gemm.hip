@@ -1056,9 +1056,16 @@ int rowA_grid_y(int rows, int cols) { return rowA_grid_y_wn(rows, cols, rowA_wn(
 int rowA_grid_y_wn(int rows, int cols, int wn) {
     const int ntiles = cdiv(cols, 32 * wn), mtiles = cdiv(rows, BM);
     const char* pe = getenv("SSDSEG_ROWA_PARTS");      // (A/B runs) cap of row-tile slots x column tiles
-    int gy = (pe != nullptr && atoi(pe) >= 64 ? atoi(pe) : 512) / ntiles;
+    // two blocks per CU for the 2-5 tile instantiations; the one-tile ones are compiled for four (three) blocks per CU
+    // (rowa_min_waves) and want them: the stem conv ran 225 us on 2048 blocks, 316 us on 512
+    const int cap = pe != nullptr && atoi(pe) >= 64 ? atoi(pe) : (wn == 1 ? 1024 : 512);
+    // few tiles (the short-M stages): one row tile per block -- 75 row tiles dealt to 51 blocks is 2 rounds instead of 1
+    if ((long long)mtiles * ntiles <= 2 * cap) return mtiles;
+    int gy = cap / ntiles;
     if (gy < 1) gy = 1;
-    return mtiles < gy ? mtiles : gy;
+    if (mtiles <= gy) return mtiles;
+    const int per = cdiv(mtiles, gy);       // row tiles per block, then as few blocks as carry them: an even deal
+    return cdiv(mtiles, per);
 }
 
 // out[m][j] = sum_z part[z][m][j] (+ residual) (+ previous out), float4 per thread, plus (optionally) the BatchNorm statistics
