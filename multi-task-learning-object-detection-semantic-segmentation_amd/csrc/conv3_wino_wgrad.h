@@ -25,7 +25,8 @@
 // act(scale * x + shift) into a ZERO-BORDERED copy [n][h+2][w+2][cin] (conv3_pad_view_kernel, ~0.35 ms for the decoder conv) --
 // applying the BatchNorm view inside the loop would cost more vector instructions than there are MFMAs.
 // The reduction over tiles is split across blocks (partials per split, summed in a fixed order by the finalize kernel).
-// Shapes: h even, w a multiple of 32 (else the caller keeps the halo-tile kernel).
+// Shapes: h even, w even (a row's last strip may be partial: its surplus dY columns are loaded as zeros); else the caller keeps the
+// halo-tile kernel.
 #pragma once
 
 constexpr int WWG_KT = 64, WWG_NT = 64;               // channels of the patch: input (rows), output (columns)
@@ -43,7 +44,8 @@ struct WinoWgArgs {
     float* part;         // [patch][slots][16][64][64]: partial dU per (patch, range of steps)
     int n, h, w, cin, cout;
     int cpatches, npatches;
-    int strips;          // w / 32
+    int strips;          // ceil(w / 32)
+    int wrem;            // output columns of a row's LAST strip (32 when w is a multiple of 32): the dY loads of the others read zeros
     int steps;           // n * (h / 2) * strips
     // Even split of patches x steps over the CUs (one 100 KB block per CU): blocks 0 .. full * patches - 1 take `span` steps of one
     // patch each (chunk-major: the blocks of a chunk read the same pixels); the remaining `tail` = steps - full * span steps of all
@@ -102,7 +104,7 @@ __global__ void __launch_bounds__(WWG_THREADS, 2) conv3_wino_wgrad_kernel(WinoWg
                 for (int e = 0; e < 16; ++e) acc[b][j][jj][e] = 0.f;
 
     // ---- DMA slots.  Input patch: 136 pixels x 16 quads = 34 wave-instructions (wave w issues w, w+8, ...); dY: 64 x 16 = 16.
-    unsigned xgo[5], ygo[2];
+    unsigned xgo[5], ygo[2], ygl[2];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
         const int pix = 4 * (wave + 8 * i) + (lane >> 4), quad = lane & 15;
@@ -116,6 +118,7 @@ __global__ void __launch_bounds__(WWG_THREADS, 2) conv3_wino_wgrad_kernel(WinoWg
         const int prow = pix >> 5, pcol = pix & 31;
         const bool ok = n0 + 4 * quad < p.cout;
         ygo[i] = ok ? (unsigned)(((prow * p.w + pcol) * p.cout + n0 + 4 * quad) * 4) : OOB;
+        ygl[i] = pcol < p.wrem ? ygo[i] : OOB;       // last strip of a row: columns beyond the image contribute Z = 0 (whatever V holds there)
     }
     // step -> byte offsets of its strip in the two tensors, advanced incrementally (all wave-uniform)
     const int hrows = p.h >> 1, nstrips = p.strips;      // (locals: a lambda that touches `p` itself can push the whole argument struct into scratch)
@@ -134,9 +137,9 @@ __global__ void __launch_bounds__(WWG_THREADS, 2) conv3_wino_wgrad_kernel(WinoWg
         _Pragma("unroll") for (int i_ = 0; i_ < 5; ++i_) {                                                              \
             if (i_ < 4 || wave_u < 2) lds_dma16(rx, (unsigned)((bb_ + 64 * (wave_u + 8 * i_) * 4) * 4), xgo[i_], xs);   \
         }                                                                                                               \
-        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                                \
-            lds_dma16(ry, (unsigned)((bb_ + WWG_X_F + 64 * (wave_u + 8 * i_) * 4) * 4), ygo[i_], ys);                   \
         const bool wrap_ = strip + 1 == nstrips, wrap2_ = wrap_ && trow + 1 == hrows;                                   \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                                                \
+            lds_dma16(ry, (unsigned)((bb_ + WWG_X_F + 64 * (wave_u + 8 * i_) * 4) * 4), wrap_ ? ygl[i_] : ygo[i_], ys); \
         xs += wrap_ ? (wrap2_ ? xs_img : xs_row) : xs_strip;                                                            \
         ys += wrap_ ? ys_row : ys_strip;                                                                                \
         strip = wrap_ ? 0 : strip + 1;                                                                                  \

@@ -1654,9 +1654,9 @@ int conv3_wino_launch(ssdseg_ctx* ctx, Conv3TArgs a, const float* w, int cin, in
 // weight gradient in the Winograd form (conv3_wino_wgrad.h): h even, w a multiple of 32, everything below 2^31 bytes
 bool conv3_wino_wgrad_takes(int n, int h, int w, int cin, int cout) {
     const int mode = conv3_wino_mode();
-    if (mode == 0 || h % 2 != 0 || w % 32 != 0) return false;
+    if (mode == 0 || h % 2 != 0 || w % 2 != 0) return false;
     if ((long long)n * (h + 2) * (w + 2) * cin * 4 >= (1LL << 31) || (long long)n * h * w * cout * 4 >= (1LL << 31)) return false;
-    return mode == 1 || (long long)n * (h / 2) * (w / 32) >= 512;
+    return mode == 1 || (long long)n * (h / 2) * cdiv(w, 32) >= 512;
 }
 
 // xsaved != nullptr: the zero-bordered activated input already exists (written by ssdseg_conv3x3_fwd_saved), `in` is not read
@@ -1665,7 +1665,8 @@ int conv3_wino_wgrad_launch(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, con
     WinoWgArgs a{};
     a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout;
     a.cpatches = cdiv(cin, WWG_KT); a.npatches = cdiv(cout, WWG_NT);
-    a.strips = w / 32;
+    a.strips = cdiv(w, 32);
+    a.wrem = w - 32 * (a.strips - 1);
     a.steps = n * (h / 2) * a.strips;
     const int patches = a.cpatches * a.npatches;
     // one block per CU (100 KB of LDS, 8 waves): patches x steps units dealt evenly (WinoWgArgs); >= 4 steps per block

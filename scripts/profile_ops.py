@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-op (per-layer) kernel timing of one engine step via the C library's HIP-event registry.
-usage: python scripts/profile_ops.py [backbone|full] [batch]  -> table sorted by time (fwd and bwd separately)"""
+usage: python scripts/profile_ops.py [backbone|full|shufflenet] [batch]  -> table sorted by time (fwd and bwd separately)"""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "multi-task-learning-object-detection-semantic-segmentation_amd"))
@@ -11,7 +11,7 @@ from ssdseglib import _hip as H
 workload = sys.argv[1] if len(sys.argv) > 1 else "backbone"
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 ctx = H.Context(0)
-step = (bench.BackboneStep if workload == "backbone" else bench.FullStep)(ctx, batch, 0, None)
+step = bench.STEPS[workload](ctx, batch, 0, None)
 for _ in range(2):
     step()
 ctx.sync()
