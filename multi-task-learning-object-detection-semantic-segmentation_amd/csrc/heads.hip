@@ -493,6 +493,75 @@ __global__ void __launch_bounds__(TL * TL) mask_head_bwd_tile_kernel(const float
     st4(dlogits + ((img * h + iy) * w + ix) * 4, acc);
 }
 
+// Larger factors (x8: ShuffleNetV2's 60 x 80 logits): a window holds (2F + F/2)^2 full-resolution pixels, so the gather is split over
+// PARTS threads per low-resolution pixel (interleaved rows, partials folded in part order: deterministic, but not the summation
+// order of the one-thread kernel) and all TL^2 * PARTS threads share the dz phase.
+template <int F, int TL, int PARTS>
+__global__ void __launch_bounds__(TL * TL * PARTS) mask_head_bwd_tile_split_kernel(const float* __restrict__ logits, int n, int h, int w,
+                                                                                     const float* __restrict__ y_true, float4 cw, float loss_scale,
+                                                                                     float* __restrict__ dlogits, int mode, const float* __restrict__ coef) {
+    constexpr int R = TL * F + F, NT = TL * TL * PARTS;
+    extern __shared__ float4 dz[];                    // [R][R] + [PARTS][TL * TL]
+    float4* red = dz + R * R;
+    const int ho = h * F, wo = w * F;
+    const float inv = 1.f / (float)F;
+    const int tiles_x = (w + TL - 1) / TL, tiles_y = (h + TL - 1) / TL;
+    int b = blockIdx.x;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y;
+    const long long img = b / tiles_y;
+    const int iy0 = ty * TL, ix0 = tx * TL;
+    const int oyb = iy0 * F - F / 2, oxb = ix0 * F - F / 2;
+    const float4 cA = mode != 0 ? ld4(coef + img * 8) : f4(0.f), cB = mode != 0 ? ld4(coef + img * 8 + 4) : f4(0.f);
+    for (int i = threadIdx.x; i < R * R; i += NT) {
+        const int ry = i / R, rx = i - ry * R;
+        const int oy = oyb + ry, ox = oxb + rx;
+        float4 v = f4(0.f);
+        if (oy >= 0 && oy < ho && ox >= 0 && ox < wo) {
+            const float4 pr = softmax4(up_logits(logits, img, h, w, oy, ox, inv, inv));
+            const float4 y = ld4(y_true + ((img * ho + oy) * wo + ox) * 4);
+            const float4 dp = mask_dp(mode, cw, y, pr, cA, cB);
+            const float dot = dp.x * pr.x + dp.y * pr.y + dp.z * pr.z + dp.w * pr.w;
+            v = make_float4(pr.x * (dp.x - dot), pr.y * (dp.y - dot), pr.z * (dp.z - dot), pr.w * (dp.w - dot));
+        }
+        dz[i] = v;
+    }
+    __syncthreads();
+    const int pix = threadIdx.x % (TL * TL), part = threadIdx.x / (TL * TL);
+    const int ly = pix / TL, lx = pix - ly * TL;
+    const int iy = iy0 + ly, ix = ix0 + lx;
+    const bool live = iy < h && ix < w;
+    float4 acc = f4(0.f);
+    if (live) {
+        int oy0 = (iy == 0) ? 0 : (iy * F - F / 2 - F), oy1 = (iy == h - 1) ? ho - 1 : (iy * F + F + F / 2 + 1);
+        int ox0 = (ix == 0) ? 0 : (ix * F - F / 2 - F), ox1 = (ix == w - 1) ? wo - 1 : (ix * F + F + F / 2 + 1);
+        oy0 = oy0 < 0 ? 0 : oy0; ox0 = ox0 < 0 ? 0 : ox0;
+        oy1 = oy1 > ho - 1 ? ho - 1 : oy1; ox1 = ox1 > wo - 1 ? wo - 1 : ox1;
+        for (int oy = oy0 + part; oy <= oy1; oy += PARTS) {
+            const float wy = lerp_weight(oy, iy, h, inv);
+            if (wy == 0.f) continue;
+            for (int ox = ox0; ox <= ox1; ++ox) {
+                const float wx = lerp_weight(ox, ix, w, inv);
+                if (wx == 0.f) continue;
+                const float4 d = dz[(oy - oyb) * R + (ox - oxb)];
+                const float wgt = wy * wx * loss_scale;
+                acc.x = fmaf(wgt, d.x, acc.x);
+                acc.y = fmaf(wgt, d.y, acc.y);
+                acc.z = fmaf(wgt, d.z, acc.z);
+                acc.w = fmaf(wgt, d.w, acc.w);
+            }
+        }
+    }
+    red[part * TL * TL + pix] = acc;
+    __syncthreads();
+    if (part == 0 && live) {
+        float4 s = red[pix];
+#pragma unroll
+        for (int q = 1; q < PARTS; ++q) { const float4 r = red[q * TL * TL + pix]; s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w; }
+        st4(dlogits + ((img * h + iy) * w + ix) * 4, s);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ SSD head gather / softmax
 // forward: out[b][off + r] = view(in)[b][r], r in [0, in_img_elems), channel of element = r % c (float4 granules)
 // reverse: in_grad[b][r] = out_grad[b][off + r]
@@ -821,6 +890,20 @@ static int mask_head_bwd_launch(ssdseg_ctx* ctx, const float* logits, int n, int
         }
         SSDSEG_LAUNCH(ctx, 16.0 * n * h * fy * wdt * fx, 0.0, (mask_head_bwd_tile_kernel<F, TL>), dim3((unsigned)blocks), dim3(TL * TL), R * R * sizeof(float4), logits, n,
                       h, wdt, y_true, make_float4(cwh[0], cwh[1], cwh[2], cwh[3]), loss_scale, dlogits, mode, coef);
+        SSDSEG_LAUNCH_CHECK();
+        return 0;
+    }
+    if (fy == 8 && fx == 8 && !(mt != nullptr && !strcmp(mt, "gather"))) {
+        constexpr int F = 8, TL = 8, PARTS = 4, R = TL * F + F;
+        constexpr size_t lds = (size_t)(R * R + PARTS * TL * TL) * sizeof(float4);
+        const long long blocks = (long long)n * cdiv(h, TL) * cdiv(wdt, TL);
+        static bool configured8 = false;
+        if (!configured8) {
+            SSDSEG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_head_bwd_tile_split_kernel<F, TL, PARTS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            configured8 = true;
+        }
+        SSDSEG_LAUNCH(ctx, 16.0 * n * h * fy * wdt * fx, 0.0, (mask_head_bwd_tile_split_kernel<F, TL, PARTS>), dim3((unsigned)blocks), dim3(TL * TL * PARTS), lds, logits, n, h,
+                      wdt, y_true, make_float4(cwh[0], cwh[1], cwh[2], cwh[3]), loss_scale, dlogits, mode, coef);
         SSDSEG_LAUNCH_CHECK();
         return 0;
     }

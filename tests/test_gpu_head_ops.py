@@ -193,8 +193,9 @@ def test_bilinear(ctx, rng, monkeypatch, n, h, w, c, fy, fx):
 
 
 @pytest.mark.parametrize("n,h,w", [(2, 12, 16), (1, 17, 35), (3, 5, 3)])     # whole 16x16 tiles; ragged tiles; smaller than one tile
-def test_mask_head(ctx, rng, monkeypatch, n, h, w):
-    c, f = 4, 4
+@pytest.mark.parametrize("f", [4, 8])
+def test_mask_head(ctx, rng, monkeypatch, n, h, w, f):
+    c = 4
     logits = rng.normal(0, 2, (n, h, w, c)).astype(np.float32)
     cls = rng.integers(0, c, (n, h * f, w * f))
     y = np.eye(c, dtype=np.float32)[cls]
@@ -219,7 +220,10 @@ def test_mask_head(ctx, rng, monkeypatch, n, h, w):
     tile = g.download()
     monkeypatch.setenv("SSDSEG_MASK_BWD", "gather")
     ctx.call("ssdseg_mask_head_bwd", dl, n, h, w, c, f, f, dy, cwh, 0.5, g)
-    np.testing.assert_array_equal(g.download(), tile)
+    if f == 4:
+        np.testing.assert_array_equal(g.download(), tile)
+    else:       # x8: the window of a pixel is folded by four threads (fixed order, but not the one-thread kernel's)
+        assert rel_err(g.download(), dlogits_ref) < 2e-5 and rel_err(g.download(), tile) < 2e-6
 
 
 @pytest.mark.parametrize("squared", [0, 1])
@@ -400,7 +404,7 @@ def test_seg_suppress(ctx, rng):
     assert np.all(out.download()[:, 2] == 0)
 
 
-def test_maxpool_shuffle_actbwd_dice(ctx, rng):
+def test_maxpool_shuffle_actbwd_dice(ctx, rng, monkeypatch):
     from ssdseglib import _hip as H
     n, h, w, c = 2, 15, 20, 24
     x = rng.normal(0, 1, (n, h, w, c)).astype(np.float32)
@@ -414,6 +418,22 @@ def test_maxpool_shuffle_actbwd_dice(ctx, rng):
     dx = ctx.empty(x.shape)
     ctx.call("ssdseg_maxpool3x3s2_bwd", H.view(dx_), ctx.array(g), dx, n, h, w, c)
     assert np.abs(dx.download() - O.maxpool3x3s2_bwd(x, g)).max() < 1e-6
+    # the two-pass form (winner codes, default) and the one-pass window scan walk the windows in the same order: bit-identical;
+    # even image sizes pad differently (SAME: (0, 1)) and a view on the input
+    for (hh, ww, view) in ((15, 20, False), (16, 22, True), (1, 1, False)):
+        xx = rng.normal(0, 1, (n, hh, ww, c)).astype(np.float32)
+        sc, shf = rng.uniform(0.5, 1.5, c).astype(np.float32), rng.normal(0, 1, c).astype(np.float32)
+        a = np.maximum(xx * sc + shf, 0).astype(np.float32) if view else xx
+        v = H.view(ctx.array(xx), ctx.array(sc), ctx.array(shf), O.ACT_RELU) if view else H.view(ctx.array(xx))
+        gg = rng.normal(0, 1, O.maxpool3x3s2_fwd(a).shape).astype(np.float32)
+        d1, d2 = ctx.empty(xx.shape), ctx.empty(xx.shape)
+        monkeypatch.delenv("SSDSEG_MAXPOOL_BWD", raising=False)
+        ctx.call("ssdseg_maxpool3x3s2_bwd", v, ctx.array(gg), d1, n, hh, ww, c)
+        monkeypatch.setenv("SSDSEG_MAXPOOL_BWD", "scan")
+        ctx.call("ssdseg_maxpool3x3s2_bwd", v, ctx.array(gg), d2, n, hh, ww, c)
+        monkeypatch.delenv("SSDSEG_MAXPOOL_BWD", raising=False)
+        assert np.array_equal(d1.download(), d2.download())
+        assert np.abs(d1.download() - O.maxpool3x3s2_bwd(a, gg)).max() < 1e-5
     sh = ctx.empty(x.shape)
     ctx.call("ssdseg_channel_shuffle", H.view(dx_), c, sh, c, n * h * w, c, 2, 0)
     assert np.array_equal(sh.download(), O.channel_shuffle(x, 2))
