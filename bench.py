@@ -10,9 +10,10 @@ Workloads (BASELINE.json `configs`):
       upstream gradients on the three tensors the heads tap, all-reduce (N > 1), Adam.
   shufflenet (configs[4], per-GPU share): the full train step on the ShuffleNetV2-1x variant.
 
-One process per GPU (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` only provides RANK /
-LOCAL_RANK / WORLD_SIZE / MASTER_*): the collective is RCCL behind our C-ABI (ssdseg_allreduce_grads), the 128-byte RCCL id
-travels through a file (ssdseglib/_parallel.py) -- no torch in this file or in the product path.  Weak scaling: each rank owns a
+One process per GPU.  `python bench.py --gpus N` starts its own N rank processes (launch_ranks: the parent touches no GPU);
+under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (which provides RANK / LOCAL_RANK / WORLD_SIZE
+/ MASTER_*) the ranks are the launcher's.  Either way the collective is RCCL behind our C-ABI (ssdseg_allreduce_grads), the
+128-byte RCCL id travels through a file handshake (ssdseglib/_parallel.py) -- no torch in this file or in the product path.  Weak scaling: each rank owns a
 32-image shard, one collective per step (gradients summed, BatchNorm moving statistics averaged).
 
 Rank 0 prints ONE JSON line with `roofline` (dominant kernel symbol; durations from HIP events recorded around every launch of
@@ -310,6 +311,50 @@ def nms_boxes_per_sec(ctx, batch, reps=20):
             "what": f"decode + combined NMS of {batch} x {a} anchors x {c} classes (incl. background), HIP events over {reps} repetitions"}
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` with no launcher around it: start N FRESH rank processes of this same script (one per GPU;
+    RANK / LOCAL_RANK / WORLD_SIZE and a private rendezvous path in their environment), relay rank 0's JSON line, return
+    non-zero if any rank did.  The parent never initialises HIP (no re-exec of a process that touched the GPU), and the children
+    are started, not exec'ed into.  When one rank dies the others would wait in the collective for ever: they are terminated (by
+    pid) and the first failure's code is returned."""
+    import shutil
+    import subprocess
+    import tempfile
+    scratch = tempfile.mkdtemp(prefix="ssdseg_bench_")
+    env = dict(os.environ, WORLD_SIZE=str(n), SSDSEG_RDZV_FILE=os.path.join(scratch, "rdzv"), SSDSEG_LAUNCHER="bench.py")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if env.get("SSDSEG_COMM") == "host":
+        env.setdefault("SSDSEG_COMM_DIR", os.path.join(scratch, "comm"))
+    procs = []
+    out0_path = os.path.join(scratch, "rank0.stdout")
+    try:
+        with open(out0_path, "wb") as out0:
+            for r in range(n):
+                procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=out0 if r == 0 else None))
+        rc, alive = 0, list(procs)
+        while alive:
+            time.sleep(0.2)
+            for p in list(alive):
+                if p.poll() is None:
+                    continue
+                alive.remove(p)
+                if p.returncode != 0 and rc == 0:
+                    rc = p.returncode
+                    print(f"bench.py: rank {procs.index(p)} exited with {p.returncode}; stopping the other ranks", file=sys.stderr)
+                    for q in alive:
+                        q.terminate()
+        with open(out0_path, "rb") as f:
+            sys.stdout.write(f.read().decode(errors="replace"))
+        sys.stdout.flush()
+        return rc if rc >= 0 else 128 - rc
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        shutil.rmtree(scratch, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -322,12 +367,15 @@ def main():
     ap.add_argument("--all-kernels", action="store_true", help="list every kernel symbol of the survey step (default: the 16 heaviest)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # nobody launched the ranks for us: this process becomes the launcher -- BEFORE anything here touches HIP
+        sys.exit(launch_ranks(args.gpus))
+
     from ssdseglib import _hip as H
     from ssdseglib import _parallel as P
     rank, local_rank, world = P.env_world()
-    if world == 1 and args.gpus > 1:
-        print(f"bench.py: --gpus {args.gpus} needs one process per GPU: launch with `python -m torch.distributed.run --nnodes=1 "
-              f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...`", file=sys.stderr)
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher's WORLD_SIZE is {world}", file=sys.stderr)
         sys.exit(2)
 
     # rehearsal switch (one-GPU box): SSDSEG_BENCH_DEVICE=0 puts every rank on one card -- then SSDSEG_COMM=host is needed too,
@@ -402,7 +450,10 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": step.workload, "global_batch": args.batch * world, "per_gpu_batch": args.batch,
-                       "parallelism": f"dp{world}", "collective": (comm.transport if comm is not None else None), "device": ctx.device_name()},
+                       "parallelism": f"dp{world}", "collective": (comm.transport if comm is not None else None),
+                       # the communicator's own idea of the group (ssdseg_comm_info for RCCL): proves the collective saw N ranks
+                       "comm_world": (comm.group_size() if comm is not None else 1), "launcher": os.environ.get("SSDSEG_LAUNCHER", "external"),
+                       "device": ctx.device_name()},
         }
         if report:
             total_ms = sum(v["ms"] for v in survey.values())           # all kernels of the survey step

@@ -148,11 +148,28 @@ int ssdseg_allreduce_grads(ssdseg_ctx* ctx, float* grads, size_t count, float* s
     ncclComm_t comm = (ncclComm_t)ctx->comm;
     const double wire = 2.0 * (ctx->comm_world - 1) / ctx->comm_world * 4.0 * ((double)count + (double)state_count);   // ring bytes per rank
     if (ctx->timing) ssdseg_timing_begin(ctx, "rccl_allreduce_grads", wire, 0.0);
-    SSDSEG_RCCL(g_rccl.GroupStart());
-    if (count) SSDSEG_RCCL(g_rccl.AllReduce(grads, grads, count, ncclFloat32, ncclSum, comm, ctx->stream));
-    if (state_count) SSDSEG_RCCL(g_rccl.AllReduce(state, state, state_count, ncclFloat32, ncclSum, comm, ctx->stream));
-    SSDSEG_RCCL(g_rccl.GroupEnd());
+    // first error wins, but the group is ALWAYS closed and the timing bracket ended: a return from inside the pair would leave
+    // this thread's RCCL group open and the next ssdseg_comm_* call silently queued into it
+    ncclResult_t first = g_rccl.GroupStart();
+    const char* where = "ncclGroupStart";
+    const bool opened = first == ncclSuccess;
+    if (first == ncclSuccess && count) {
+        first = g_rccl.AllReduce(grads, grads, count, ncclFloat32, ncclSum, comm, ctx->stream);
+        where = "ncclAllReduce(grads)";
+    }
+    if (first == ncclSuccess && state_count) {
+        first = g_rccl.AllReduce(state, state, state_count, ncclFloat32, ncclSum, comm, ctx->stream);
+        where = "ncclAllReduce(state)";
+    }
+    if (opened) {
+        const ncclResult_t end = g_rccl.GroupEnd();
+        if (first == ncclSuccess && end != ncclSuccess) {
+            first = end;
+            where = "ncclGroupEnd";
+        }
+    }
     if (ctx->timing) ssdseg_timing_end(ctx);
+    if (first != ncclSuccess) return rccl_fail(first, where);
     if (state_count) {
         const int blocks = (int)((state_count + 255) / 256 < 1024 ? (state_count + 255) / 256 : 1024);
         SSDSEG_LAUNCH(ctx, 8.0 * state_count, 0.0, scale_inplace_kernel, dim3(blocks), dim3(256), 0, state, state_count, 1.0f / (float)ctx->comm_world);

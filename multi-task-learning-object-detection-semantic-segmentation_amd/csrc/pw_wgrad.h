@@ -16,6 +16,9 @@
 // committing to LDS ([pixel][channel], the natural layout: no swizzle needed -- a wave's read is one contiguous run), two LDS
 // buffers, one barrier per step.  Rows past the end of a split are zeroed on the dy side only (a zero factor is enough).
 #pragma once
+#ifndef PWW_B128
+#define PWW_B128 0
+#endif
 
 struct PwWgArgs {
     const float* x;      // [M][ldx] raw input
@@ -257,6 +260,23 @@ __global__ void __launch_bounds__(512, 2) pw_wgrad_kernel(PwWgArgs p) {
                 f2 v;
                 v.x = acc[a][0][e]; v.y = acc[a][JY > 1 ? 1 : 0][e];
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), rp, off, so, 0);
+            } else if (PWW_B128) {
+                typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                f4 v;
+                v.x = acc[a][0][e]; v.y = acc[a][JY > 1 ? 1 : 0][e]; v.z = acc[a][JY > 2 ? 2 : 0][e]; v.w = acc[a][JY > 3 ? 3 : 0][e];
+                if (PWW_B128 == 3) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), rp, ok ? lane_off + (unsigned)so : OOB, 0, 0);
+                } else {
+                    if (PWW_B128 == 2) {
+                        const unsigned long long pp = (unsigned long long)p.part;
+                        u4 rs;
+                        rs.x = (unsigned)pp; rs.y = (unsigned)(pp >> 32) & 0xffffu; rs.z = p.part_bytes; rs.w = 0x00020000u;
+                        asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n s_nop 1" : : "v"(__builtin_bit_cast(u4, v)), "v"(off), "s"(rs), "s"(so) : "memory");
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), rp, off, so, 0);
+                    }
+                }
             } else {
                 // two 8-byte stores: a single 16-byte buffer store of the four outputs gave wrong values in the last four lanes of
                 // every sixteen at large slab counts (measured on gfx950, scripts/dbg/pww.py; not understood), the pair is exact

@@ -139,7 +139,9 @@ _SIGNATURES = {
 
 
 def library_path() -> str:
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+    """the in-tree library; SSDSEG_LIB names another build of the SAME sources (A/B experiments of scripts/dbg: e.g. a kernel
+    compiled with a different store form) -- never a fallback: a missing file is an error either way"""
+    return os.environ.get("SSDSEG_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
 
 
 def load_library():

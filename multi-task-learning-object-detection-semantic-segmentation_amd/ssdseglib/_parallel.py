@@ -9,8 +9,10 @@ weights never need a broadcast after step 0.  The result equals the mean of `wor
 from the same weights.
 
 No torch here: the collective is RCCL behind the C-ABI (`ssdseg_comm_*`, `ssdseg_allreduce_grads`, csrc/comm.hip).  The only
-host-side exchange is the 128-byte RCCL unique id, passed through a file keyed by the launcher's environment
-(`python -m torch.distributed.run` only provides RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT to this code).  xGMI is
+host-side exchange is the 128-byte RCCL unique id, passed through a file handshake (`exchange_bytes`: fresh random bytes
+from both sides, so a stale file of a crashed launch is never taken for this one's) at a path keyed by the launcher's
+environment: `bench.py --gpus N` starts its own N rank processes and names the path (SSDSEG_RDZV_FILE); under
+`python -m torch.distributed.run` (which only provides RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT) it is derived from those.  xGMI is
 point-to-point (7 links x ~153 GB/s), a 16 MB ring all-reduce is ~0.2 ms against a >= 25 ms step, so a single flat bucket
 is the right granularity (no bucketing / overlap machinery is worth its launches here).
 
@@ -70,30 +72,89 @@ def rendezvous_path() -> str:
     return os.path.join(tempfile.gettempdir(), f"ssdseg_rdzv_{key}")
 
 
-def exchange_bytes(rank: int, payload: Optional[bytes], nbytes: int, path: Optional[str] = None, timeout_s: float = 300.0) -> bytes:
-    """rank 0 publishes `payload` (atomically: write + rename), everybody else waits for the file and reads it"""
+NONCE_BYTES = 16
+
+
+def _publish(path: str, data: bytes) -> None:
+    """atomic: write to a private name, fsync, rename"""
+    tmp = f"{path}.{os.getpid()}.tmp"
+    with open(tmp, "wb") as f:
+        f.write(data)
+        f.flush()
+        os.fsync(f.fileno())
+    os.replace(tmp, path)
+
+
+def _read(path: str) -> bytes:
+    try:
+        with open(path, "rb") as f:
+            return f.read()
+    except OSError:
+        return b""
+
+
+def rendezvous_cleanup(path: str) -> None:
+    """remove the files of a (finished or crashed) rendezvous on `path`"""
+    import glob
+    for p in [path, path + ".go"] + glob.glob(glob.escape(path) + ".ack*"):
+        try:
+            os.unlink(p)
+        except OSError:
+            pass
+
+
+def exchange_bytes(rank: int, payload: Optional[bytes], nbytes: int, path: Optional[str] = None, timeout_s: float = 300.0,
+                   world: int = 2) -> bytes:
+    """rank 0's `payload` (nbytes) reaches every other rank of THIS launch, through three kinds of small files next to `path`.
+
+    A bare "rank 0 writes, the others read whatever is there" is not safe: a crashed earlier launch with the same path leaves a
+    stale id behind, a later rank > 0 reads it before rank 0 republishes and then blocks in ncclCommInitRank for ever.  So the
+    exchange is a handshake in which every side proves freshness with random bytes made in THIS process:
+      rank 0: removes whatever is at `path` / `path.go` / `path.ack*`, publishes `path` = nonce | payload, waits until every
+              rank k has published `path.ack<k>` = nonce | token_k for THIS nonce, then publishes `path.go` = nonce | token_1 |
+              ... | token_{world-1};
+      rank k: draws token_k once; acknowledges every new nonce it sees at `path`; returns the payload read together with the
+              acknowledged nonce only when `path.go` names that nonce AND echoes token_k -- a stale `path` or `path.go` can do
+              neither.
+    No clocks involved.  TimeoutError (with the path and what was missing) after `timeout_s`; callers exit non-zero on it."""
     path = path or rendezvous_path()
+    deadline = time.monotonic() + timeout_s
     if rank == 0:
         assert payload is not None and len(payload) == nbytes
-        tmp = f"{path}.{os.getpid()}.tmp"
-        with open(tmp, "wb") as f:
-            f.write(payload)
-            f.flush()
-            os.fsync(f.fileno())
-        os.replace(tmp, path)
+        rendezvous_cleanup(path)
+        nonce = os.urandom(NONCE_BYTES)
+        _publish(path, nonce + payload)
+        tokens = {}
+        while len(tokens) < world - 1:
+            for k in range(1, world):
+                if k not in tokens:
+                    ack = _read(f"{path}.ack{k}")
+                    if len(ack) == 2 * NONCE_BYTES and ack[:NONCE_BYTES] == nonce:
+                        tokens[k] = ack[NONCE_BYTES:]
+            if len(tokens) < world - 1:
+                if time.monotonic() > deadline:
+                    missing = [k for k in range(1, world) if k not in tokens]
+                    raise TimeoutError(f"rank 0: ranks {missing} never acknowledged the rendezvous at {path} within {timeout_s:.0f} s "
+                                       f"(did they start, and with the same SSDSEG_RDZV_FILE / launcher?)")
+                time.sleep(0.005)
+        _publish(path + ".go", nonce + b"".join(tokens[k] for k in range(1, world)))
         return payload
-    deadline = time.monotonic() + timeout_s
+    token = os.urandom(NONCE_BYTES)
+    acked, current = None, None
     while True:
-        try:
-            with open(path, "rb") as f:
-                data = f.read()
-            if len(data) == nbytes:
-                return data
-        except FileNotFoundError:
-            pass
+        data = _read(path)
+        if len(data) == NONCE_BYTES + nbytes and data[:NONCE_BYTES] != acked:
+            acked, current = data[:NONCE_BYTES], data[NONCE_BYTES:]
+            _publish(f"{path}.ack{rank}", acked + token)
+        if acked is not None:
+            go = _read(path + ".go")
+            lo = NONCE_BYTES * rank
+            if len(go) == NONCE_BYTES * world and go[:NONCE_BYTES] == acked and go[lo:lo + NONCE_BYTES] == token:
+                return current
         if time.monotonic() > deadline:
-            raise TimeoutError(f"rank {rank}: no rendezvous file {path} after {timeout_s:.0f} s (did rank 0 start?)")
-        time.sleep(0.01)
+            raise TimeoutError(f"rank {rank}: rendezvous at {path} not completed within {timeout_s:.0f} s "
+                               f"({'no file from rank 0' if acked is None else 'rank 0 never confirmed (stale file of an earlier launch?)'})")
+        time.sleep(0.005)
 
 
 class RcclComm:
@@ -111,14 +172,17 @@ class RcclComm:
             H._check(lib.ssdseg_comm_unique_id(buf, ID_BYTES), "ssdseg_comm_unique_id")
             ident = buf.raw
         path = path or rendezvous_path()
-        ident = exchange_bytes(self.rank, ident, ID_BYTES, path) if self.world > 1 else ident
+        timeout = float(os.environ.get("SSDSEG_RDZV_TIMEOUT", "300"))
+        ident = exchange_bytes(self.rank, ident, ID_BYTES, path, timeout, self.world) if self.world > 1 else ident
         H._check(lib.ssdseg_comm_init_rank(ctx.handle, ident, ID_BYTES, self.rank, self.world), "ssdseg_comm_init_rank")
         if self.rank == 0 and self.world > 1:
-            # init_rank is collective: once it has returned here every rank has read the id
-            try:
-                os.unlink(path)
-            except OSError:
-                pass
+            rendezvous_cleanup(path)        # init_rank is collective: once it has returned here every rank holds the id
+
+    def group_size(self) -> int:
+        """the world size the RCCL communicator itself reports (ssdseg_comm_info)"""
+        r, w = C.c_int(-1), C.c_int(-1)
+        H._check(self.ctx.lib.ssdseg_comm_info(self.ctx.handle, C.byref(r), C.byref(w)), "ssdseg_comm_info")
+        return int(w.value)
 
     def allreduce_grads(self, grads: H.DeviceBuffer, state: Optional[H.DeviceBuffer] = None):
         """in place: grads <- SUM over ranks, state <- MEAN over ranks; stream-ordered, no host sync"""
@@ -184,6 +248,10 @@ class HostStagedComm:
         if self.round > 2 and os.path.exists(old):
             os.unlink(old)
         return out
+
+    def group_size(self) -> int:
+        """number of ranks that actually took part in an exchange (counted, not configured)"""
+        return len(self._exchange(np.zeros(1)))
 
     def allreduce_array(self, arr: np.ndarray, mean: bool = False) -> np.ndarray:
         parts = self._exchange(np.ascontiguousarray(arr))

@@ -126,7 +126,7 @@ def _host_worker(rank, world, global_batch, comm_dir, out_dir, rdzv):
     from ssdseglib import _parallel as P
     # the 128-byte rendezvous the RCCL path uses (rank 0 publishes, the others poll)
     ident = bytes(range(128)) if rank == 0 else None
-    got = P.exchange_bytes(rank, ident, 128, rdzv, timeout_s=60)
+    got = P.exchange_bytes(rank, ident, 128, rdzv, timeout_s=60, world=world)
     assert got == bytes(range(128))
     comm = P.init_comm(None)
     assert comm.transport == "host" and comm.world == world
@@ -144,6 +144,10 @@ def test_two_rank_host_staged_transport_and_rendezvous(tmp_path):
     world, global_batch = 2, 6
     comm_dir, out_dir = tmp_path / "comm", tmp_path / "out"
     out_dir.mkdir()
+    # a crashed earlier launch left its id, its go file and an acknowledgement behind at the same path: nobody may take them
+    (tmp_path / "rdzv").write_bytes(b"S" * 16 + b"\xee" * 128)
+    (tmp_path / "rdzv.go").write_bytes(b"S" * 16 + b"T" * 16)
+    (tmp_path / "rdzv.ack1").write_bytes(b"S" * 16 + b"T" * 16)
     mpctx = multiprocessing.get_context("spawn")
     procs = [mpctx.Process(target=_host_worker, args=(r, world, global_batch, str(comm_dir), str(out_dir), str(tmp_path / "rdzv")))
              for r in range(world)]
@@ -159,6 +163,49 @@ def test_two_rank_host_staged_transport_and_rendezvous(tmp_path):
     assert np.allclose(r0[mean_g.size:], mean_s, rtol=0, atol=1e-14)
 
 
+def test_rendezvous_handshake_ignores_stale_files_and_times_out(tmp_path):
+    """the 128-byte id exchange: three ranks as threads; ranks > 0 start FIRST and find a complete stale exchange
+    (id + go + their own old acknowledgement) at the path; they must come back with rank 0's fresh payload, not the stale one.
+    Without a rank 0 the others time out with a message instead of returning the stale id."""
+    import threading
+    from ssdseglib import _parallel as P
+    path = str(tmp_path / "rdzv")
+    stale = b"N" * P.NONCE_BYTES
+
+    def seed_stale():
+        (tmp_path / "rdzv").write_bytes(stale + b"\x55" * 128)
+        (tmp_path / "rdzv.go").write_bytes(stale + b"A" * 16 + b"B" * 16)
+        (tmp_path / "rdzv.ack1").write_bytes(stale + b"A" * 16)
+        (tmp_path / "rdzv.ack2").write_bytes(stale + b"B" * 16)
+
+    seed_stale()
+    fresh = bytes(range(128))
+    got = {}
+
+    def run(rank, delay):
+        import time as _t
+        _t.sleep(delay)
+        try:
+            got[rank] = P.exchange_bytes(rank, fresh if rank == 0 else None, 128, path, timeout_s=30, world=3)
+        except Exception as e:        # noqa: BLE001 - reported through the assertion below
+            got[rank] = e
+
+    threads = [threading.Thread(target=run, args=(r, 0.0 if r else 0.3)) for r in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(60)
+    assert got == {0: fresh, 1: fresh, 2: fresh}, got
+    P.rendezvous_cleanup(path)
+    assert not list(tmp_path.glob("rdzv*"))
+
+    seed_stale()                       # rank 0 never shows up: the stale files alone do not complete a handshake
+    with pytest.raises(TimeoutError, match="stale file"):
+        P.exchange_bytes(1, None, 128, path, timeout_s=0.5, world=3)
+    with pytest.raises(TimeoutError, match="never acknowledged"):
+        P.exchange_bytes(0, fresh, 128, str(tmp_path / "other"), timeout_s=0.3, world=2)
+
+
 def test_unknown_transport_and_missing_dir_are_errors(monkeypatch):
     from ssdseglib import _parallel as P
     monkeypatch.setenv("WORLD_SIZE", "2")
@@ -170,3 +217,23 @@ def test_unknown_transport_and_missing_dir_are_errors(monkeypatch):
     monkeypatch.setenv("SSDSEG_COMM", "smoke-signals")
     with pytest.raises(ValueError, match="unknown"):
         P.init_comm(None)
+
+
+def test_bench_launcher_without_a_gpu_fails_loudly_and_cleans_up(tmp_path):
+    """`python bench.py --gpus 2` here (no GPU): the parent launches two rank processes without touching HIP itself, both die at
+    Context creation (no CPU fallback), the launcher reports the first failure, stops the rest and returns non-zero -- no hang,
+    no JSON line, no leftover rendezvous directory."""
+    import subprocess
+    import tempfile
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "SSDSEG_RDZV_FILE")}
+    env["TMPDIR"] = str(tmp_path)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    err = r.stderr.decode(errors="replace")
+    assert r.returncode != 0 and "exited with" in err, err[-2000:]
+    assert not [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert not list(tmp_path.glob("ssdseg_bench_*"))
+    # a launcher-provided world that disagrees with --gpus is an argument error, not a silent single-rank run
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE is 2" in r.stderr.decode()

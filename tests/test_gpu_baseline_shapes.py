@@ -288,12 +288,15 @@ def test_depthwise_at_baseline_shape(ctx, n, h, w, c, s):
 
 
 # ------------------------------------------------------------------------------------------------ dense 3x3 (K6)
-def test_conv3x3_decoder_at_baseline_shape(ctx):
-    """blocks.py:117 at batch 32: 32x120x160x304 -> 256 (860.7 GFLOP per direction)"""
+@pytest.mark.parametrize("h,w", [(120, 160), (60, 80)])
+def test_conv3x3_decoder_at_baseline_shape(ctx, h, w):
+    """blocks.py:117 at batch 32: 32x120x160x304 -> 256 (MobileNetV2, 860.7 GFLOP per direction) and 32x60x80x304 -> 256
+    (ShuffleNetV2: the decoder taps stage 2 at 60x80, models.py:748 -- the Winograd weight gradient then runs rows whose last
+    32-column strip is partial: 80 = 2 * 32 + 16)"""
     from ssdseglib import _hip as H
-    n, h, w, cin, cout = 32, 120, 160, 304, 256
+    n, cin, cout = 32, 304, 256
     m = n * h * w
-    rng = np.random.default_rng(304256)
+    rng = np.random.default_rng(304256 + h)
     x, sc, sh = view_inputs(rng, (n, h, w, cin))
     wgt = (rng.normal(0, 1, (3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
     w64 = wgt.astype(np.float64)
@@ -370,10 +373,14 @@ def test_conv3x3_decoder_at_baseline_shape(ctx):
 
 
 # ------------------------------------------------------------------------------------------------ whole step, batch 32, 480x640
-def test_full_train_step_batch32_480x640_properties(ctx):
+@pytest.mark.parametrize("workload", ["full", "shufflenet"])
+def test_full_train_step_batch32_480x640_properties(ctx, workload):
+    """configs[2] (MobileNetV2) and configs[4]'s per-GPU share (ShuffleNetV2-1x, reference quirk Q1 kept: the heads' ReLU(max 0)
+    makes every class probability 0.25, so the hard-negative pool is ONE big tie -- the selection is then decided purely by the
+    lowest-index-first rule, on the device and in the oracle)"""
     import bench
     from ssdseglib import _hip as H
-    step = bench.FullStep(ctx, 32, 0, None)
+    step = bench.STEPS[workload](ctx, 32, 0, None)
     eng = step.eng
     P = eng.P
     p0 = P["params"].download(); s0 = P["state"].download()

@@ -107,3 +107,25 @@ def test_two_process_step_equals_mean_of_two_single_steps(ctx, tmp_path):
     want, _, _ = O.adam_step(p0.astype(np.float32), mean, np.zeros_like(p0), np.zeros_like(p0), 1, lr=1e-3)
     assert np.abs(r0["params"] - want).max() < 2e-6
     assert not np.array_equal(r0["params"], p0)
+
+
+def test_bench_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus N` with no launcher around it starts its own N fresh rank processes and prints
+    rank 0's line.  Rehearsed on the one card of this box: both ranks on device 0, explicit host-staged transport (RCCL refuses
+    two ranks on one device) -- the launch, rendezvous directory, barriers, max-over-ranks timing and the collective's place in
+    the step are the ones the 8-GPU run uses; only the transport differs, and the line says so."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "SSDSEG_RDZV_FILE", "SSDSEG_COMM_DIR")}
+    env.update(SSDSEG_BENCH_DEVICE="0", SSDSEG_COMM="host")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+                        "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-4000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak"
+    cfg = out["config"]
+    assert cfg["collective"] == "host" and cfg["comm_world"] == 2 and cfg["launcher"] == "bench.py"
+    assert cfg["global_batch"] == 8 and cfg["parallelism"] == "dp2"
+    assert np.isfinite(out["value"]) and out["value"] > 0 and np.isfinite(out["ms_per_step"])
+    assert "rccl_allreduce_grads" not in json.dumps(out)        # the host transport never claims to be RCCL
