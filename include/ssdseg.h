@@ -92,6 +92,13 @@ int ssdseg_ctx_side(ssdseg_ctx* ctx, int on);
 /* enabled == 0: everything on the ctx stream from now on (used by bench.py to time a kernel without a co-running neighbour);
  * enabled != 0: side stream back on (if the ctx has one). */
 int ssdseg_ctx_side_enable(ssdseg_ctx* ctx, int enabled);
+/* Deferred column sums.  Weight-gradient kernels split their reduction over pixel ranges and leave partial slabs that a
+ * fixed-order column sum folds into dW; nothing reads dW before the optimizer (Keras `train_step`: gradients are consumed by
+ * `optimizer.apply_gradients`, NB03#cell16), so with enabled != 0 those ~80 small launches per backward pass are recorded
+ * instead of launched and go out as ONE launch at the next join (ssdseg_ctx_join, and every entry point that joins: sync, copies,
+ * all-reduce, Adam).  Same summation order either way: gradients are bit-identical with deferral on or off.
+ * enabled == 0 flushes what is pending and returns to one launch per column sum. */
+int ssdseg_colsum_defer(ssdseg_ctx* ctx, int enabled);
 int ssdseg_ctx_reserve(ssdseg_ctx* ctx, size_t workspace_bytes);
 int ssdseg_ctx_device_name(ssdseg_ctx* ctx, char* buf_host, size_t buf_len);
 int ssdseg_malloc(ssdseg_ctx* ctx, size_t bytes, void** out_host);

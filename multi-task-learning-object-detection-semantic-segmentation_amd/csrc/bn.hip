@@ -18,7 +18,8 @@ constexpr int RTHREADS = 256;   // small blocks: they have to find room next to 
 // CH: independent chains (= loads in flight) per lane and value: 4 for the two-value BatchNorm tables, 8 for the column sums of the
 // weight-gradient slabs (tall tables read once: latency is all there is)
 template <int NV, int RC, int CH = 4>
-__device__ __forceinline__ void reduce_parts(const float* __restrict__ part, int nparts, int c, int ch, double (&tot)[NV], double* red) {
+__device__ __forceinline__ void reduce_parts(const float* __restrict__ part, int nparts, int c, int ch, double (&tot)[NV], double* red,
+                                             const int tx = threadIdx.x, const int ty = threadIdx.y) {
     constexpr int RP = RTHREADS / RC;
     double acc[NV][CH];
 #pragma unroll
@@ -26,7 +27,7 @@ __device__ __forceinline__ void reduce_parts(const float* __restrict__ part, int
 #pragma unroll
         for (int u = 0; u < CH; ++u) acc[v][u] = 0.0;
     if (ch < c) {
-        int p = threadIdx.y;
+        int p = ty;
         for (; p + (CH - 1) * RP < nparts; p += CH * RP) {
             float f[NV][CH];
 #pragma unroll
@@ -51,24 +52,24 @@ __device__ __forceinline__ void reduce_parts(const float* __restrict__ part, int
 #pragma unroll
             for (int u = 0; u < CH; u += 4) s += (acc[v][u] + acc[v][u + 1]) + (acc[v][u + 2] + acc[v][u + 3]);
         }
-        red[(v * RP + threadIdx.y) * (RC + 1) + threadIdx.x] = s;
+        red[(v * RP + ty) * (RC + 1) + tx] = s;
     }
     __syncthreads();
     // fold RP -> 8 lanes in parallel, then serially (fixed order either way)
     for (int half = RP / 2; half >= 8; half >>= 1) {
-        if ((int)threadIdx.y < half) {
+        if ((int)ty < half) {
 #pragma unroll
             for (int v = 0; v < NV; ++v)
-                red[(v * RP + threadIdx.y) * (RC + 1) + threadIdx.x] += red[(v * RP + threadIdx.y + half) * (RC + 1) + threadIdx.x];
+                red[(v * RP + ty) * (RC + 1) + tx] += red[(v * RP + ty + half) * (RC + 1) + tx];
         }
         __syncthreads();
     }
-    if (threadIdx.y == 0) {
+    if (ty == 0) {
         constexpr int LAST = RP < 8 ? RP : 8;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             double s = 0.0;
-            for (int y = 0; y < LAST; ++y) s += red[(v * RP + y) * (RC + 1) + threadIdx.x];
+            for (int y = 0; y < LAST; ++y) s += red[(v * RP + y) * (RC + 1) + tx];
             tot[v] = s;
         }
     }
@@ -213,6 +214,41 @@ __global__ void __launch_bounds__(RTHREADS) colsum_kernel(const float* __restric
     if (threadIdx.y == 0 && l < len) out[l] = (float)tot[0];
 }
 
+// Deferred column sums: every weight-gradient slab table of a backward pass in ONE launch.  Block b belongs to the entry whose
+// block range contains it and does there exactly what a colsum_kernel<rc> block does (same lanes per column, same chains, same
+// fold), so a gradient is the same bits whether its column sum was launched on its own or rides in the batch.
+struct ColsumEntry {
+    const float* part;
+    float* out;
+    int nparts, len, rc, block_begin;
+};
+
+__global__ void __launch_bounds__(RTHREADS) colsum_batch_kernel(const ColsumEntry* __restrict__ table, int n) {
+    __shared__ double red[(RTHREADS / 2) * 3];       // the largest of the three shapes: (RTHREADS / RC) * (RC + 1) at RC = 2
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {                                 // last entry with block_begin <= blockIdx.x (block-uniform)
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].block_begin <= (int)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const ColsumEntry e = table[lo];
+    const int lb = (int)blockIdx.x - e.block_begin, t = threadIdx.x;
+    double tot[1] = {0.0};
+    if (e.rc == 2) {
+        const int tx = t & 1, ty = t >> 1, l = lb * 2 + tx;
+        reduce_parts<1, 2, 8>(e.part, e.nparts, e.len, l, tot, red, tx, ty);
+        if (ty == 0 && l < e.len) e.out[l] = (float)tot[0];
+    } else if (e.rc == 8) {
+        const int tx = t & 7, ty = t >> 3, l = lb * 8 + tx;
+        reduce_parts<1, 8, 8>(e.part, e.nparts, e.len, l, tot, red, tx, ty);
+        if (ty == 0 && l < e.len) e.out[l] = (float)tot[0];
+    } else {
+        const int tx = t & 31, ty = t >> 5, l = lb * 32 + tx;
+        reduce_parts<1, 32, 8>(e.part, e.nparts, e.len, l, tot, red, tx, ty);
+        if (ty == 0 && l < e.len) e.out[l] = (float)tot[0];
+    }
+}
+
 __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift, int act,
                                 int ldx, const float* __restrict__ rx, const float* __restrict__ rscale, const float* __restrict__ rshift,
                                 int ract, int ldr, float* __restrict__ out, int ldo, long long m, int cv) {
@@ -306,11 +342,76 @@ int ssdseg_bn_bwd_finalize_launch(ssdseg_ctx* ctx, const float* part, int nparts
     return 0;
 }
 
-int ssdseg_colsum(ssdseg_ctx* ctx, const float* part, int nparts, long long len, float* out) {
+// ---------------------------------------------------------------------------------------------- deferred column sums
+// Nothing reads a weight gradient before the optimizer (or the all-reduce in front of it), so the ~80 column sums that fold the
+// partial slabs of the weight-gradient kernels need not be ~80 launches scattered over the backward pass: while deferral is on,
+// the slabs live in a persistent arena (ssdseg_partials), ssdseg_colsum only records (slab table, destination), and the first
+// ssdseg_join afterwards -- the engine joins the side stream at the end of backward() -- folds them all with one launch.
+#include <vector>
+
+struct ssdseg_defer {
+    struct Chunk { char* base; size_t cap, used; };
+    bool on = false;
+    std::vector<Chunk> chunks;
+    std::vector<ColsumEntry> pending, uploaded;
+    ColsumEntry* d_table = nullptr;
+    size_t d_cap = 0;
+    double pending_bytes = 0.0;
+};
+
+static bool defer_owns(const ssdseg_defer* d, const void* p) {
+    for (const auto& c : d->chunks)
+        if ((const char*)p >= c.base && (const char*)p < c.base + c.cap) return true;
+    return false;
+}
+
+int ssdseg_partials(ssdseg_ctx* ctx, size_t bytes, void** out) {
+    ssdseg_defer* d = ctx->defer;
+    if (d == nullptr || !d->on) return ssdseg_workspace(ctx, bytes, out);
+    bytes = (bytes + 255) & ~(size_t)255;
+    for (auto& c : d->chunks) {
+        if (c.cap - c.used >= bytes) {
+            *out = c.base + c.used;
+            c.used += bytes;
+            return 0;
+        }
+    }
+    ssdseg_defer::Chunk c;
+    c.cap = bytes > ((size_t)256 << 20) ? bytes : ((size_t)256 << 20);
+    c.used = bytes;
+    void* p = nullptr;
+    SSDSEG_HIP(hipMalloc(&p, c.cap));
+    c.base = (char*)p;
+    d->chunks.push_back(c);
+    *out = p;
+    return 0;
+}
+
+static int colsum_rc(int nparts, long long len) {
     // wide tables (weight-gradient slabs: thousands of columns) fill the chip with 32-column blocks as well, and those read whole
     // 128-byte lines of every partial row instead of 32-byte pieces (SSDSEG_COLSUM_RC=8 restores the narrow blocks for A/B runs)
     const char* e = getenv("SSDSEG_COLSUM_RC");
-    const int rc = (len >= 4096 && !(e != nullptr && e[0] == '8')) ? 32 : reduce_rc(nparts, len);
+    return (len >= 4096 && !(e != nullptr && e[0] == '8')) ? 32 : reduce_rc(nparts, len);
+}
+
+int ssdseg_colsum(ssdseg_ctx* ctx, const float* part, int nparts, long long len, float* out) {
+    const int rc = colsum_rc(nparts, len);
+    ssdseg_defer* d = ctx->defer;
+    if (d != nullptr && d->on && defer_owns(d, part)) {
+        // a destination recorded twice before a flush (an op repeated by a profiling script): the column sum OVERWRITES its
+        // destination, so the later table supersedes the earlier one -- drop the earlier entry
+        for (size_t i = 0; i < d->pending.size(); ++i)
+            if (d->pending[i].out == out) {
+                d->pending_bytes -= 4.0 * d->pending[i].nparts * (double)d->pending[i].len;
+                d->pending.erase(d->pending.begin() + i);
+                break;
+            }
+        ColsumEntry e;
+        e.part = part; e.out = out; e.nparts = nparts; e.len = (int)len; e.rc = rc; e.block_begin = 0;
+        d->pending.push_back(e);
+        d->pending_bytes += 4.0 * nparts * (double)len;
+        return 0;
+    }
     const dim3 grid(cdiv(len, rc)), block(rc, RTHREADS / rc);
     if (rc == 2) SSDSEG_LAUNCH_NAMED(ctx, "colsum_kernel", 4.0 * nparts * len, 0.0, colsum_kernel<2>, grid, block, 0, part, nparts, (int)len, out);
     else if (rc == 8) SSDSEG_LAUNCH_NAMED(ctx, "colsum_kernel", 4.0 * nparts * len, 0.0, colsum_kernel<8>, grid, block, 0, part, nparts, (int)len, out);
@@ -319,7 +420,69 @@ int ssdseg_colsum(ssdseg_ctx* ctx, const float* part, int nparts, long long len,
     return 0;
 }
 
+int ssdseg_colsum_flush(ssdseg_ctx* ctx) {
+    ssdseg_defer* d = ctx->defer;
+    if (d == nullptr) return 0;
+    if (d->pending.empty()) {
+        for (auto& c : d->chunks) c.used = 0;
+        return 0;
+    }
+    // called with the side stream joined and launches going to the main stream: every slab is complete in stream order
+    int blocks = 0;
+    for (auto& e : d->pending) {
+        e.block_begin = blocks;
+        blocks += cdiv(e.len, e.rc);
+    }
+    const size_t n = d->pending.size();
+    if (n > d->d_cap) {
+        SSDSEG_HIP(hipStreamSynchronize(ctx->stream));
+        if (d->d_table) SSDSEG_HIP(hipFree(d->d_table));
+        d->d_table = nullptr;
+        d->d_cap = 0;
+        void* p = nullptr;
+        SSDSEG_HIP(hipMalloc(&p, (n + 64) * sizeof(ColsumEntry)));
+        d->d_table = (ColsumEntry*)p;
+        d->d_cap = n + 64;
+        d->uploaded.clear();
+    }
+    // a training loop repeats the same pass: same arena offsets, same table -> nothing to upload after the first step
+    const bool same = d->uploaded.size() == n && memcmp(d->uploaded.data(), d->pending.data(), n * sizeof(ColsumEntry)) == 0;
+    if (!same) {
+        d->uploaded = d->pending;     // (pageable source: the runtime has staged it when the call returns)
+        SSDSEG_HIP(hipMemcpyAsync(d->d_table, d->uploaded.data(), n * sizeof(ColsumEntry), hipMemcpyHostToDevice, ctx->stream));
+    }
+    SSDSEG_LAUNCH(ctx, d->pending_bytes, 0.0, colsum_batch_kernel, dim3((unsigned)blocks), dim3(RTHREADS), 0, d->d_table, (int)n);
+    d->pending.clear();
+    d->pending_bytes = 0.0;
+    for (auto& c : d->chunks) c.used = 0;     // the next pass's slabs are written by kernels queued behind this launch
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+void ssdseg_defer_destroy(ssdseg_ctx* ctx) {
+    ssdseg_defer* d = ctx->defer;
+    if (d == nullptr) return;
+    for (auto& c : d->chunks) (void)hipFree(c.base);
+    if (d->d_table) (void)hipFree(d->d_table);
+    delete d;
+    ctx->defer = nullptr;
+}
+
 extern "C" {
+
+int ssdseg_colsum_defer(ssdseg_ctx* ctx, int enabled) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    if (ctx->defer == nullptr) {
+        if (!enabled) return 0;
+        ctx->defer = new ssdseg_defer();
+    }
+    if (!enabled) {
+        int rc = ssdseg_join(ctx);      // flushes what is pending
+        if (rc) return rc;
+    }
+    ctx->defer->on = enabled != 0;
+    return 0;
+}
 
 int ssdseg_bn_finalize(ssdseg_ctx* ctx, const float* stats, int nparts, int c, double count, const float* gamma,
                        const float* beta, float eps, float momentum, float* moving_mean, float* moving_var, float* mean,

@@ -37,6 +37,8 @@ struct ssdseg_ctx {
     // RCCL communicator of this rank (comm.hip; ncclComm_t behind a void* so that only comm.hip needs the RCCL header)
     void* comm;
     int comm_rank, comm_world;
+    // deferred column sums of weight-gradient partial slabs (bn.hip: ssdseg_colsum_defer / ssdseg_colsum_flush)
+    struct ssdseg_defer* defer;
 };
 
 extern "C" {
@@ -71,6 +73,13 @@ void ssdseg_set_error(const char* fmt, ...);
 int ssdseg_hip_fail(hipError_t e, const char* what);
 // workspace of at least `bytes` (grows with hipMalloc)
 int ssdseg_workspace(ssdseg_ctx* ctx, size_t bytes, void** out);
+// storage for the partial slabs / rows a later ssdseg_colsum reads: the stream's workspace, or -- while column sums are deferred
+// (ssdseg_colsum_defer) -- a persistent arena whose regions live until the flush (bn.hip)
+int ssdseg_partials(ssdseg_ctx* ctx, size_t bytes, void** out);
+// launches the pending column sums of a deferred backward pass as ONE kernel on the ctx stream (called by ssdseg_join once the
+// side stream has been joined); no-op when nothing is pending
+int ssdseg_colsum_flush(ssdseg_ctx* ctx);
+void ssdseg_defer_destroy(ssdseg_ctx* ctx);
 
 #define SSDSEG_HIP(call)                                      \
     do {                                                      \

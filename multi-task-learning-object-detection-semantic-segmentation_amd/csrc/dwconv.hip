@@ -403,7 +403,7 @@ int dw_bwd_impl(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, const ss
         const int nparts = (int)ml.grid.x;
         const bool fuse = bn != nullptr && dilation == 1 && dx != nullptr;   // (with accumulate: this conv is the LAST writer of dx)
         void* ws;
-        int rc = ssdseg_workspace(ctx, (size_t)nparts * 11 * c * sizeof(float), &ws);
+        int rc = ssdseg_partials(ctx, (size_t)nparts * 11 * c * sizeof(float), &ws);
         if (rc) return rc;
         float* part = (float*)ws;
         float* bnpart = part + (size_t)nparts * 9 * c;
@@ -436,7 +436,7 @@ int dw_bwd_impl(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, const ss
         const int nparts = (int)ml.grid.x;
         const bool fuse = bn != nullptr && dx != nullptr;
         void* ws;
-        int rc = ssdseg_workspace(ctx, (size_t)nparts * 11 * c * sizeof(float), &ws);
+        int rc = ssdseg_partials(ctx, (size_t)nparts * 11 * c * sizeof(float), &ws);
         if (rc) return rc;
         float* part = (float*)ws;
         float* bnpart = part + (size_t)nparts * 9 * c;
@@ -471,7 +471,7 @@ int dw_bwd_impl(ssdseg_ctx* ctx, const ssdseg_view* in, const float* w, const ss
     const int nparts = use_lds ? (int)ll.grid.x : (int)l.grid.x;
     void* ws;
     size_t part_bytes = (size_t)nparts * 9 * c * sizeof(float);
-    int rc = ssdseg_workspace(ctx, part_bytes, &ws);
+    int rc = ssdseg_partials(ctx, part_bytes, &ws);
     if (rc) return rc;
     float* part = (float*)ws;
 #define DW_BWD_LDS(S_, PT_, PL_) \

@@ -1328,7 +1328,7 @@ int pw_wgrad_launch(ssdseg_ctx* ctx, PwWgArgs a, float* dw) {
     float* part = dw;
     if (slabs > 1) {
         void* ws;
-        int rc = ssdseg_workspace(ctx, pb, &ws);
+        int rc = ssdseg_partials(ctx, pb, &ws);
         if (rc) return rc;
         part = (float*)ws;
     }
@@ -1360,7 +1360,8 @@ bool pw_wgrad_enabled() {
 // -> 0 launched, < 0 not taken (the caller falls back), > 0 error
 int pw_wgrad_try(ssdseg_ctx* ctx, const WGradArgs& w, float* dw) {
     if (!pw_wgrad_enabled() || w.stem || w.convH > 0 || w.K % 4 != 0 || w.N % 4 != 0 || w.ldx % 4 != 0 || w.ldy % 4 != 0) return -1;
-    if ((long long)w.M * w.ldx * 4 >= (1LL << 31) || (long long)w.M * w.ldy * 4 >= (1LL << 31)) return -1;
+    // the pipelined issue() prefetches one step (<= 64 rows) past the end of a split and forms m0 * ld * 4 in 32 bits
+    if (((long long)w.M + 64) * w.ldx * 4 >= (1LL << 31) || ((long long)w.M + 64) * w.ldy * 4 >= (1LL << 31)) return -1;
     PwWgArgs a{};
     a.x = w.x; a.xs = w.xs; a.xt = w.xt; a.xact = w.xact; a.ldx = w.ldx;
     a.g = w.g; a.y = w.y; a.gs = w.gs; a.gt = w.gt; a.gk1 = w.gk1; a.gk0 = w.gk0; a.gact = w.gact; a.ldy = w.ldy;
@@ -1427,7 +1428,7 @@ int wgrad_run(ssdseg_ctx* ctx, WGradArgs a, float* dw) {
     float* part = dw;
     if (splits > 1) {
         void* ws;
-        int rc = ssdseg_workspace(ctx, (size_t)splits * k * n * sizeof(float), &ws);
+        int rc = ssdseg_partials(ctx, (size_t)splits * k * n * sizeof(float), &ws);
         if (rc) return rc;
         part = (float*)ws;
     }
@@ -1865,7 +1866,7 @@ int ssdseg_pwconv_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssd
     int gy = 2 * ctx->num_cus;   // two resident blocks per CU (112 + 16*NT registers each); every block walks >= 1 row tile
     if (gy > mtiles) gy = mtiles;
     void* ws;
-    int rc = ssdseg_workspace(ctx, (size_t)gy * k * n * sizeof(float), &ws);
+    int rc = ssdseg_partials(ctx, (size_t)gy * k * n * sizeof(float), &ws);
     if (rc) return rc;
     a.wpart = (float*)ws;
     const dim3 grid(1, gy, 1);
@@ -2442,7 +2443,7 @@ int ssdseg_conv3x3_bwd_weight(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, c
         a.x_bytes = (unsigned)((((long long)n * h * wdt - 1) * ldx + cin) * 4);
         a.g_bytes = (unsigned)((long long)n * h * wdt * cout * 4);
         void* ws;
-        int rc = ssdseg_workspace(ctx, (size_t)splits * 9 * cin * cout * sizeof(float), &ws);
+        int rc = ssdseg_partials(ctx, (size_t)splits * 9 * cin * cout * sizeof(float), &ws);
         if (rc) return rc;
         a.part = (float*)ws;
         static bool configured = false;   // dynamic LDS beyond 64 KiB has to be announced once
@@ -2477,7 +2478,7 @@ int ssdseg_conv3x3_bwd_weight(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, c
         a.steps_per_split = (a.steps + splits - 1) / splits;
         splits = (a.steps + a.steps_per_split - 1) / a.steps_per_split;
         void* ws;
-        int rc = ssdseg_workspace(ctx, (size_t)splits * 9 * cin * cout * sizeof(float), &ws);
+        int rc = ssdseg_partials(ctx, (size_t)splits * 9 * cin * cout * sizeof(float), &ws);
         if (rc) return rc;
         a.part = (float*)ws;
         const dim3 grid(gx, gy, (unsigned)splits);

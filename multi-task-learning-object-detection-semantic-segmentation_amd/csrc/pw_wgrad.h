@@ -16,8 +16,10 @@
 // committing to LDS ([pixel][channel], the natural layout: no swizzle needed -- a wave's read is one contiguous run), two LDS
 // buffers, one barrier per step.  Rows past the end of a split are zeroed on the dy side only (a zero factor is enough).
 #pragma once
-#ifndef PWW_B128
-#define PWW_B128 0
+// store form of the JY == 4 epilogue: 3 (default) one 16-byte store with an immediate soffset | 0 two 8-byte stores | 1, 2: the
+// two forms of scripts/dbg/b128_experiment.sh (1 reproduces the round-2 wrong results)
+#ifndef PWW_STORE
+#define PWW_STORE 3
 #endif
 
 struct PwWgArgs {
@@ -260,32 +262,38 @@ __global__ void __launch_bounds__(512, 2) pw_wgrad_kernel(PwWgArgs p) {
                 f2 v;
                 v.x = acc[a][0][e]; v.y = acc[a][JY > 1 ? 1 : 0][e];
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), rp, off, so, 0);
-            } else if (PWW_B128) {
-                typedef unsigned u4 __attribute__((ext_vector_type(4)));
-                typedef float f4 __attribute__((ext_vector_type(4)));
-                f4 v;
-                v.x = acc[a][0][e]; v.y = acc[a][JY > 1 ? 1 : 0][e]; v.z = acc[a][JY > 2 ? 2 : 0][e]; v.w = acc[a][JY > 3 ? 3 : 0][e];
-                if (PWW_B128 == 3) {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), rp, ok ? lane_off + (unsigned)so : OOB, 0, 0);
-                } else {
-                    if (PWW_B128 == 2) {
-                        const unsigned long long pp = (unsigned long long)p.part;
-                        u4 rs;
-                        rs.x = (unsigned)pp; rs.y = (unsigned)(pp >> 32) & 0xffffu; rs.z = p.part_bytes; rs.w = 0x00020000u;
-                        asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n s_nop 1" : : "v"(__builtin_bit_cast(u4, v)), "v"(off), "s"(rs), "s"(so) : "memory");
-                    } else {
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), rp, off, so, 0);
-                    }
-                }
-            } else {
-                // two 8-byte stores: a single 16-byte buffer store of the four outputs gave wrong values in the last four lanes of
-                // every sixteen at large slab counts (measured on gfx950, scripts/dbg/pww.py; not understood), the pair is exact
+            } else if (PWW_STORE == 0) {
+                // two 8-byte stores (no more than 64 bits of data per store: outside the hazard below)
                 typedef unsigned u2 __attribute__((ext_vector_type(2)));
                 typedef float f2 __attribute__((ext_vector_type(2)));
                 f2 v, w2;
                 v.x = acc[a][0][e]; v.y = acc[a][JY > 1 ? 1 : 0][e]; w2.x = acc[a][JY > 2 ? 2 : 0][e]; w2.y = acc[a][JY > 3 ? 3 : 0][e];
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), rp, off, so, 0);
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, w2), rp, off, so + 8, 0);
+            } else {
+                // ONE 16-byte store of the lane's four outputs, with the row offset folded into the VECTOR offset (soffset 0).
+                // Round 2 had the row offset in an SGPR soffset and saw wrong values in the last four lanes of every sixteen.  Cause
+                // (round 3; scripts/micro/store_x4_hazard.hip, profiles/r03_store_x4_hazard.txt): on gfx950 a buffer store of more
+                // than 64 bits reads its data registers late -- a VALU write of those registers needs TWO wait states after the
+                // store, an SGPR soffset buys ONE.  hipcc inserts the two when soffset is an immediate and nothing when it is a
+                // register (LLVM GCNHazardRecognizer::createsVALUHazard exempts MUBUF stores with a register soffset), and here
+                // the compiler recycles a data register for the next row's index in the very next slot (`buffer_store_dwordx4
+                // v[0:3], v18, s[28:31], s2 offen` / `v_or_b32 v0, 2, v70`).  With an immediate soffset the compiler keeps its own
+                // two wait states; scripts/check_store_hazard.py scans the built library for the register-soffset pattern.
+                typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                f4 v;
+                v.x = acc[a][0][e]; v.y = acc[a][JY > 1 ? 1 : 0][e]; v.z = acc[a][JY > 2 ? 2 : 0][e]; v.w = acc[a][JY > 3 ? 3 : 0][e];
+                if (PWW_STORE == 1) {            // the round-2 form, kept for the experiment only: HAZARDOUS
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), rp, off, so, 0);
+                } else if (PWW_STORE == 2) {     // the same store followed by one wait state, as inline assembly: exact
+                    const unsigned long long pp = (unsigned long long)p.part;
+                    u4 rs;
+                    rs.x = (unsigned)pp; rs.y = (unsigned)(pp >> 32) & 0xffffu; rs.z = p.part_bytes; rs.w = 0x00020000u;
+                    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n s_nop 1" : : "v"(__builtin_bit_cast(u4, v)), "v"(off), "s"(rs), "s"(so) : "memory");
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), rp, ok ? lane_off + (unsigned)so : OOB, 0, 0);
+                }
             }
         }
 }

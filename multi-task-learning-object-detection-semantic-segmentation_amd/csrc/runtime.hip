@@ -219,6 +219,7 @@ int ssdseg_ctx_create(int device, void* stream, ssdseg_ctx** out_host) {
     c->comm = nullptr;
     c->comm_rank = 0;
     c->comm_world = 1;
+    c->defer = nullptr;
     if (stream) {
         c->stream = (hipStream_t)stream;
         c->owns_stream = false;
@@ -269,11 +270,13 @@ void ssdseg_side_end(ssdseg_ctx* c) {
 
 int ssdseg_join(ssdseg_ctx* c) {
     if (c->side_on) ssdseg_side_end(c);
-    if (!c->side_pending) return 0;
-    SSDSEG_HIP(hipEventRecord(c->ev_join, c->side_stream));
-    SSDSEG_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
-    c->side_pending = false;
-    return 0;
+    if (c->side_pending) {
+        SSDSEG_HIP(hipEventRecord(c->ev_join, c->side_stream));
+        SSDSEG_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        c->side_pending = false;
+    }
+    // whoever joins is about to read gradients: the deferred column sums of the weight-gradient slabs go out now, as one launch
+    return c->defer != nullptr ? ssdseg_colsum_flush(c) : 0;
 }
 
 int ssdseg_ctx_destroy(ssdseg_ctx* ctx) {
@@ -283,6 +286,7 @@ int ssdseg_ctx_destroy(ssdseg_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->comm) (void)ssdseg_comm_destroy(ctx);
     ssdseg_timing_enable(ctx, 0);
+    ssdseg_defer_destroy(ctx);
     if (ctx->workspace) (void)hipFree(ctx->workspace);
     if (ctx->side_workspace) (void)hipFree(ctx->side_workspace);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);

@@ -1182,7 +1182,14 @@ class Engine:
         if self.training:
             self._sync_padded("p", to_bucket=True, which="state")   # moving statistics of padded BatchNorms -> bucket
 
+    def _defer_colsums(self):
+        """the column sums that fold the weight-gradient partial slabs are recorded during the pass and launched ONCE by the
+        join at its end (include/ssdseg.h: ssdseg_colsum_defer); SSDSEG_COLSUM_DEFER=0 keeps one launch per layer (A/B runs,
+        bit-identical results)"""
+        self.ctx.colsum_defer(os.environ.get("SSDSEG_COLSUM_DEFER", "1") != "0")
+
     def backward(self):
+        self._defer_colsums()
         for s in self.stores:
             s.gwritten = False
         for s in self.stores:
@@ -1210,6 +1217,7 @@ class Engine:
             v.store.gwritten = True
 
     def backward_from_outputs(self):
+        self._defer_colsums()
         for s in self.stores:
             s.gwritten = False
         self.mark_output_grads_written()
@@ -1527,6 +1535,12 @@ class _CompactLoader:
         self.anchors = ctx.array(corners.astype(np.float32))
         if self.det is not None and self.anchors.shape[0] != self.det.y_boxes.shape[1]:
             raise ValueError(f"encoder has {self.anchors.shape[0]} default boxes, the model's heads {self.det.y_boxes.shape[1]}")
+        # ssdseg_encode_targets writes (batch, anchors, encoder.num_classes) floats into the labels target and the mask is
+        # expanded to encoder.num_classes planes (reference datacoder.py:332): both buffers are sized by the MODEL's channels
+        if self.det is not None and int(encoder.num_classes) != self.det.y_labels.shape[-1]:
+            raise ValueError(f"encoder.num_classes = {encoder.num_classes}, the model's labels head has {self.det.y_labels.shape[-1]} classes")
+        if self.mask_op is not None and int(encoder.num_classes) != self.mask_op.y_true.shape[-1]:
+            raise ValueError(f"encoder.num_classes = {encoder.num_classes}, the model's mask head has {self.mask_op.y_true.shape[-1]} classes")
         self.staged = None
         self._keep = None
 

@@ -46,6 +46,7 @@ _SIGNATURES = {
     "ssdseg_ctx_join": [_vp],
     "ssdseg_ctx_side": [_vp, _i],
     "ssdseg_ctx_side_enable": [_vp, _i],
+    "ssdseg_colsum_defer": [_vp, _i],
     "ssdseg_ctx_reserve": [_vp, _sz],
     "ssdseg_ctx_device_name": [_vp, C.c_char_p, _sz],
     "ssdseg_malloc": [_vp, _sz, C.POINTER(_vp)],
@@ -353,6 +354,10 @@ class Context:
 
     def side_enable(self, enabled: bool):
         _check(self.lib.ssdseg_ctx_side_enable(self.handle, 1 if enabled else 0), "ssdseg_ctx_side_enable")
+
+    def colsum_defer(self, enabled: bool):
+        """record the column sums of weight-gradient slabs and fold them with one launch at the next join (include/ssdseg.h)"""
+        _check(self.lib.ssdseg_colsum_defer(self.handle, 1 if enabled else 0), "ssdseg_colsum_defer")
 
     def reserve(self, nbytes: int):
         _check(self.lib.ssdseg_ctx_reserve(self.handle, int(nbytes)), "ssdseg_ctx_reserve")

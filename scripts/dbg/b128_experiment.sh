@@ -1,7 +1,7 @@
 #!/bin/bash
 # one GPU pass that pins the 16-byte-store anomaly of pw_wgrad_kernel<1,4,1,1>.
 #   (1) scripts/micro/store_x4_hazard: the store + overwrite in inline assembly with 0/1/2 wait states, SGPR vs immediate soffset
-#   (2) scripts/dbg/pww.py on four builds of the library (scripts/dbg/lib, made by hand from the same sources with -DPWW_B128=n):
+#   (2) scripts/dbg/pww.py on four builds of the library (scripts/dbg/lib, made by hand from the same sources with -DPWW_STORE=n (0 for the two-store build)):
 #       default (two 8-byte stores), 1 = one b128 store with SGPR soffset as the compiler schedules it, 2 = the same store
 #       followed by s_nop 1 (inline asm), 3 = b128 store with the row offset in voffset (immediate soffset 0: the compiler's own
 #       hazard recogniser then keeps two wait states)

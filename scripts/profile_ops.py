@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Per-op (per-layer) kernel timing of one engine step via the C library's HIP-event registry.
+"""Per-op (per-layer) kernel timing of one engine step via the C library's HIP-event registry, every kernel ALONE on the chip:
+the weight-gradient side stream is disabled (ctx.side_enable(False)), so no row carries a co-running neighbour.  Each op runs REP
+times; a row is one kernel symbol of one op: launches per op call, microseconds per op call (all its launches), and the rates of
+the AVERAGE LAUNCH (algorithmic bytes / flops per launch over the launch's duration).
 usage: python scripts/profile_ops.py [backbone|full|shufflenet] [batch]  -> table sorted by time (fwd and bwd separately)"""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,6 +20,7 @@ for _ in range(2):
 ctx.sync()
 eng = step.eng
 rows = []
+ctx.side_enable(False)          # weight gradients on the main stream: nothing co-runs with the kernel being timed
 ctx.timing(True)
 REP = 3
 for direction in ("fwd", "bwd"):
@@ -35,11 +39,15 @@ for direction in ("fwd", "bwd"):
         rep = ctx.timing_report()
         for k, v in rep.items():
             if v["ms"] <= 0: continue
-            ms = v["ms"] / REP
-            rows.append((ms, direction, op.name or type(op).__name__, k, v["bytes"] / v["count"], v["flops"] / v["count"], v["count"] // REP))
+            assert v["count"] % REP == 0, (op.name, k, v["count"])     # every repeat launches the same kernels
+            per_call = v["count"] // REP                                # launches of this symbol per op call
+            ms_launch = v["ms"] / v["count"]                            # average launch
+            rows.append((v["ms"] / REP, direction, op.name or type(op).__name__, k, v["bytes"] / v["count"], v["flops"] / v["count"], per_call, ms_launch))
 ctx.timing(False)
+ctx.side_enable(True)
 rows.sort(reverse=True)
 total = sum(r[0] for r in rows)
 print(f"total kernel ms/step {total:.3f}")
-for ms, d, name, k, b, f, cnt in rows[:int(os.environ.get('TOP', '60'))]:
-    print(f"{ms*1e3:9.1f} us {d} {name:44s} {k:44s} x{cnt} {b/ms/1e6:8.0f} GB/s {f/ms/1e9:7.1f} TF")
+print("   us/op-call dir op                                           kernel                                       launches  us/launch      GB/s     TF   (rates: per launch)")
+for ms, d, name, k, b, f, cnt, msl in rows[:int(os.environ.get('TOP', '60'))]:
+    print(f"{ms*1e3:9.1f} us {d} {name:44s} {k:44s} x{cnt} {msl*1e3:9.1f} {b/msl/1e6:8.0f} GB/s {f/msl/1e9:7.1f} TF")

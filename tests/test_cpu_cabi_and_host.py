@@ -231,3 +231,17 @@ def test_rgb_augmentation_against_colorsys(rng):
     aug, t = D.augmentation_rgb_channels(x, targets)
     assert t is targets and aug.dtype == np.float32 and aug.min() >= 0.0 and aug.max() <= 255.0
     assert np.abs(aug - x).max() < 60.0
+
+
+def test_no_register_soffset_store_data_hazard_in_the_built_library():
+    """gfx950 needs two wait states between a buffer store of more than 64 bits and a VALU write of its data registers; hipcc
+    inserts none when the store's soffset is an SGPR (round 2's wrong lanes 12-15 in csrc/pw_wgrad.h; pinned by
+    scripts/micro/store_x4_hazard.hip, profiles/r03_store_x4_hazard.txt).  The built library must not contain the pattern."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_store_hazard", os.path.join(REPO, "scripts", "check_store_hazard.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    from ssdseglib import _hip
+    stores, findings = mod.scan(_hip.library_path())
+    assert stores > 0, "the scan found no wide buffer store at all: has the disassembly format changed?"
+    assert not findings, findings

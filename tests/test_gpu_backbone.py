@@ -99,3 +99,37 @@ def test_backbone_forward_backward_parity(ctx, rng, kernel_family, batch, shape)
         eng.seed_output_grad(i, g)
     eng.backward_from_outputs()
     assert np.array_equal(g1, eng.P["grads"].download())
+
+
+def test_deferred_column_sums_are_bit_identical_and_one_launch(ctx, rng, monkeypatch):
+    """the column sums that fold weight-gradient partial slabs go out as ONE launch at the join that ends the
+    backward pass (ssdseg_colsum_defer) instead of one per layer.  Same lanes, chains and fold order per column as the
+    per-layer kernel: the gradient bucket is the same bits with deferral on and off; the kernel registry shows the launch counts."""
+    from ssdseglib import _engine as E
+    model = build_backbone((96, 128, 3))
+    eng = E.Engine(model, 3, training=True, ctx=ctx)
+    x = rng.integers(0, 256, (3, 96, 128, 3)).astype(np.float32)
+    seeds = [rng.normal(0, 1, (3,) + tuple(t.shape[1:])).astype(np.float32) for t in model.outputs]
+
+    def run(defer):
+        monkeypatch.setenv("SSDSEG_COLSUM_DEFER", "1" if defer else "0")
+        eng.set_input(x)
+        eng.forward()
+        for i, g in enumerate(seeds):
+            eng.seed_output_grad(i, g)
+        ctx.timing(True)
+        ctx.timing_reset()
+        eng.backward_from_outputs()
+        rep = ctx.timing_report()
+        ctx.timing(False)
+        return eng.P["grads"].download(), rep
+
+    g_off, rep_off = run(False)
+    g_on, rep_on = run(True)
+    g_off2, _ = run(False)
+    assert np.isfinite(g_on).all() and np.abs(g_on).max() > 0
+    assert np.array_equal(g_on, g_off) and np.array_equal(g_off, g_off2)
+    assert rep_off.get("colsum_kernel", {"count": 0})["count"] > 20 and "colsum_batch_kernel" not in rep_off
+    assert rep_on["colsum_batch_kernel"]["count"] == 1
+    assert rep_on.get("colsum_kernel", {"count": 0})["count"] <= 4        # (consumed-at-once tables keep their own launch)
+    ctx.colsum_defer(False)

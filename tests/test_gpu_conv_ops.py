@@ -156,6 +156,8 @@ PW_CASES = [
     (70001, 96, 264),    # >= 65536 rows: the eight-wave tile GEMM (pw_tile.h), ragged last row tile, two 132-column tiles forward
     (66000, 256, 256),   # eight-wave tile GEMM, one 256-column tile forward / two 128-column tiles backward (the decoder sepconv shape)
     (300, 72, 40),       # tile GEMM with a reduction that is not a multiple of 32 (72 = 2 steps + 8) and a single ragged column tile
+    (153600, 32, 192),   # weight gradient on pw_wgrad_kernel<1,4,1,1> at a large split count: the shape (with 70001 x 24 x 144) on which a
+                         # 16-byte store with an SGPR soffset returned wrong lanes 12-15 of every 16 in round 2 (gfx950 store-data hazard)
     (66000, 176, 72),    # input gradient with 176 output columns at >= 65,536 rows: the 4 x 2 wave grid with three-tile waves (88 ragged columns per wave group)
 ]
 

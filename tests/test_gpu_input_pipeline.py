@@ -165,3 +165,13 @@ def test_compact_batch_errors(ctx, rng):
     crowded = ssdseglib.datacoder.CompactBatch(cb.images, cb.mask_index, [np.tile(cb.ground_truth[0][:1], (65, 1)), cb.ground_truth[1]], cb.flip, cb.encoder)
     with pytest.raises(ValueError, match="64"):
         model.train_on_batch(crowded)
+    # an encoder built for another class count than the model's heads: the encode kernel would overrun / mis-stride the target
+    # buffers -- refused when the loader is made
+    import copy
+    enc5 = copy.copy(cb.encoder)
+    enc5.num_classes = 5
+    wrong = ssdseglib.datacoder.CompactBatch(cb.images, cb.mask_index, cb.ground_truth, cb.flip, enc5)
+    _, _, model2 = build(seed=5)
+    _compile(model2)
+    with pytest.raises(ValueError, match="num_classes"):
+        model2.train_on_batch(wrong)
