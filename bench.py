@@ -150,10 +150,18 @@ class FullStep:
                 "confidence+mining / localization losses + bwd (+all-reduce) + Adam), batch 32/GPU, 480x640x3, 9600 anchors, 4 classes")
 
     kind = "mobilenetv2"
+    fix_q1 = False
 
     def __init__(self, ctx, batch, rank, reducer):
         from ssdseglib import _engine as E
         boxes, self.model = build_full_model(self.kind)
+        if self.fix_q1:
+            # SURVEY.md 8(d) config 5 allows either form: the reference's ShuffleNetV2 builder calls the head blocks without
+            # relu_max_value, i.e. ReLU(max_value=0.0) (quirk Q1) -- every head activation and EVERY gradient of the model is then
+            # exactly zero.  "Fixed": those layers clip at 6 like the MobileNetV2 variant's (what the author evidently meant).
+            for l in self.model.layers:
+                if type(l).__name__ == "ReLU" and l.max_value == 0.0:
+                    l.max_value = 6.0
         self.eng = E.Engine(self.model, batch, training=True, ctx=ctx)
         self.eng.configure_losses(self.model._compiled["loss"], self.model._compiled["loss_weights"])
         self.reducer, self.ctx, self.batch = reducer, ctx, batch
@@ -184,7 +192,14 @@ class ShuffleNetStep(FullStep):
     kind = "shufflenetv2"
 
 
-STEPS = {"backbone": BackboneStep, "full": FullStep, "shufflenet": ShuffleNetStep}
+class ShuffleNetFixedStep(ShuffleNetStep):
+    """the same with quirk Q1 fixed (heads' ReLU6 instead of ReLU(max_value=0.0)): gradients are non-zero, kernel work identical"""
+    workload = ShuffleNetStep.workload.replace("reference quirk Q1 (heads' ReLU max_value 0.0) kept bug-compatible",
+                                               "reference quirk Q1 FIXED (heads' ReLU max_value 6.0 instead of 0.0), so that gradients are non-zero")
+    fix_q1 = True
+
+
+STEPS = {"backbone": BackboneStep, "full": FullStep, "shufflenet": ShuffleNetStep, "shufflenet-q1fixed": ShuffleNetFixedStep}
 
 
 def cpu_baseline(workload, sample_batch=1):
@@ -200,7 +215,11 @@ def cpu_baseline(workload, sample_batch=1):
         outs = ref.forward(x, training=True)
         gouts = [(rng.standard_normal(o.shape, dtype=np.float32) * np.float32(1e-3)) for o in outs]
     else:
-        boxes, model = build_full_model("shufflenetv2" if workload == "shufflenet" else "mobilenetv2")
+        boxes, model = build_full_model("shufflenetv2" if workload.startswith("shufflenet") else "mobilenetv2")
+        if workload == "shufflenet-q1fixed":
+            for l in model.layers:
+                if type(l).__name__ == "ReLU" and l.max_value == 0.0:
+                    l.max_value = 6.0
         gt, cnt, mask = synthetic_ground_truth(sample_batch, 11)
         ref = NpModel(model, dtype=np.float32)
         corners = boxes.get_boxes_coordinates_corners('ssd')
@@ -370,7 +389,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
-    ap.add_argument("--workload", default="full", choices=["backbone", "full", "shufflenet"])
+    ap.add_argument("--workload", default="full", choices=list(STEPS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events in the timed region")
     ap.add_argument("--all-kernels", action="store_true", help="list every kernel symbol of the survey step (default: the 16 heaviest)")

@@ -352,6 +352,7 @@ int ssdseg_bn_bwd_finalize_launch(ssdseg_ctx* ctx, const float* part, int nparts
 struct ssdseg_defer {
     struct Chunk { char* base; size_t cap, used; };
     bool on = false;
+    int hold = 0;          // > 0: a composite entry point consumes the nested result at once -- no deferral (ssdseg_defer_hold)
     std::vector<Chunk> chunks;
     std::vector<ColsumEntry> pending, uploaded;
     ColsumEntry* d_table = nullptr;
@@ -367,7 +368,7 @@ static bool defer_owns(const ssdseg_defer* d, const void* p) {
 
 int ssdseg_partials(ssdseg_ctx* ctx, size_t bytes, void** out) {
     ssdseg_defer* d = ctx->defer;
-    if (d == nullptr || !d->on) return ssdseg_workspace(ctx, bytes, out);
+    if (d == nullptr || !d->on || d->hold > 0) return ssdseg_workspace(ctx, bytes, out);
     bytes = (bytes + 255) & ~(size_t)255;
     for (auto& c : d->chunks) {
         if (c.cap - c.used >= bytes) {
@@ -397,7 +398,7 @@ static int colsum_rc(int nparts, long long len) {
 int ssdseg_colsum(ssdseg_ctx* ctx, const float* part, int nparts, long long len, float* out) {
     const int rc = colsum_rc(nparts, len);
     ssdseg_defer* d = ctx->defer;
-    if (d != nullptr && d->on && defer_owns(d, part)) {
+    if (d != nullptr && d->on && d->hold == 0 && defer_owns(d, part)) {
         // a destination recorded twice before a flush (an op repeated by a profiling script): the column sum OVERWRITES its
         // destination, so the later table supersedes the earlier one -- drop the earlier entry
         for (size_t i = 0; i < d->pending.size(); ++i)
@@ -457,6 +458,10 @@ int ssdseg_colsum_flush(ssdseg_ctx* ctx) {
     for (auto& c : d->chunks) c.used = 0;     // the next pass's slabs are written by kernels queued behind this launch
     SSDSEG_LAUNCH_CHECK();
     return 0;
+}
+
+void ssdseg_defer_hold(ssdseg_ctx* ctx, int delta) {
+    if (ctx->defer != nullptr) ctx->defer->hold += delta;
 }
 
 void ssdseg_defer_destroy(ssdseg_ctx* ctx) {

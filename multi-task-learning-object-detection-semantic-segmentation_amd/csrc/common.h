@@ -80,6 +80,10 @@ int ssdseg_partials(ssdseg_ctx* ctx, size_t bytes, void** out);
 // side stream has been joined); no-op when nothing is pending
 int ssdseg_colsum_flush(ssdseg_ctx* ctx);
 void ssdseg_defer_destroy(ssdseg_ctx* ctx);
+// A composite entry point whose nested weight-gradient call writes a SCRATCH result it consumes right away (the narrow 3x3 conv's
+// tap-expanded dW2, repacked into dW by the next kernel) brackets that call with hold(+1) / hold(-1): column sums recorded in
+// between are launched at once, as without deferral.
+void ssdseg_defer_hold(ssdseg_ctx* ctx, int delta);
 
 #define SSDSEG_HIP(call)                                      \
     do {                                                      \

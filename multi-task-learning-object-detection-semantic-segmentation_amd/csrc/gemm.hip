@@ -2415,7 +2415,9 @@ int ssdseg_conv3x3_bwd_weight(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, c
         a.g = dz; a.ldy = nc;
         a.M = (int)m; a.K = cin; a.N = nc;
         ctx->ws_reserved += wb + zb;
+        ssdseg_defer_hold(ctx, +1);           // dw2 is scratch, repacked right below: its column sum cannot wait for the flush
         rc = wgrad_run(ctx, a, dw2);
+        ssdseg_defer_hold(ctx, -1);
         ctx->ws_reserved -= wb + zb;
         if (rc) return rc;
         SSDSEG_LAUNCH(ctx, 8.0 * 9 * cin * cout, 0.0, conv3n_pack_w_kernel, dim3(cdiv(9 * cin * cout, 256)), dim3(256), 0, (const float*)dw, dw2, cin, cout, 1);
