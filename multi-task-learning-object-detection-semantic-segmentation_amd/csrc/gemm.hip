@@ -1305,6 +1305,14 @@ int launch_wgrad_wn(ssdseg_ctx* ctx, const WGradArgs& a, int wn, dim3 grid) {
     return 0;
 }
 
+// partial slabs of a split weight gradient (splits * K * N floats, written once and read once by the column sum) are kept below this
+// fraction of the layer's operand traffic M * (K + N)  (SSDSEG_WGRAD_SLAB_FRAC, read per call: A/B runs)
+double slab_fraction() {
+    const char* e = getenv("SSDSEG_WGRAD_SLAB_FRAC");
+    const double f = e != nullptr ? atof(e) : 0.5;
+    return f > 0.0 ? f : 0.5;
+}
+
 // ---- pointwise weight gradient, row-naming form (pw_wgrad.h).  SSDSEG_PW_WGRAD=0: gemm_wgrad_kernel for everything.
 template <int JX, int JY, int WK, int WN>
 int pw_wgrad_launch(ssdseg_ctx* ctx, PwWgArgs a, float* dw) {
@@ -1314,7 +1322,7 @@ int pw_wgrad_launch(ssdseg_ctx* ctx, PwWgArgs a, float* dw) {
     // blocks: two per CU; every split >= 4 steps; partial slabs (splits * K * N, written and re-read) below half the operand traffic
     long long splits = (2LL * ctx->num_cus + (long long)ktiles * ntiles - 1) / ((long long)ktiles * ntiles);
     const long long cap_steps = (steps + 3) / 4;
-    const long long cap_traffic = (long long)((double)a.M * (a.K + a.N) / (2.0 * a.K * a.N));
+    const long long cap_traffic = (long long)((double)a.M * (a.K + a.N) * slab_fraction() / ((double)a.K * a.N));
     if (splits > cap_steps) splits = cap_steps;
     if (splits > cap_traffic) splits = cap_traffic;
     if (splits < 1) splits = 1;
@@ -1406,7 +1414,7 @@ int wgrad_run(ssdseg_ctx* ctx, WGradArgs a, float* dw) {
     // split the reduction rows so that (a) the chip is full, (b) every block still does >= 4 steps and (c) the partial
     // slabs (splits*k*n floats, written then re-read) stay below half of the operand traffic m*(k+n)
     long long max_splits = (steps + 3) / 4;
-    const long long traffic_cap = (long long)((double)m * (k + n) / (2.0 * k * n));
+    const long long traffic_cap = (long long)((double)m * (k + n) * slab_fraction() / ((double)k * n));
     if (max_splits > traffic_cap) max_splits = traffic_cap < 1 ? 1 : traffic_cap;
     int wn = pick_wn(n, (long long)itiles * max_splits);
     // the 4-way row-split shape stages 64 x (32*wn) of (g, y) per step: beyond 3 column tiles it needs > 256 VGPRs (1 wave/SIMD)
@@ -1863,7 +1871,11 @@ int ssdseg_pwconv_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssd
     a.I = m; a.R = n; a.J = k;
     a.xw = in->x; a.xws = in->scale; a.xwt = in->shift; a.xwact = in->act; a.ldxw = ldx;
     const int mtiles = cdiv(m, BM);
-    int gy = 2 * ctx->num_cus;   // two resident blocks per CU (112 + 16*NT registers each); every block walks >= 1 row tile
+    const int nt = cdiv(n, 32);
+    const size_t wl = wres_enabled() ? wres_lds_bytes(n, 1) : 0;
+    // two resident blocks per CU (112 + 16*NT registers each); every block walks >= 1 row tile.  (Round 3: three blocks per CU for
+    // NT <= 3 -- 168 registers, 12 waves per CU -- left the block-1 expand backward at 0.642 ms: not short of waves in flight.)
+    int gy = 2 * ctx->num_cus;
     if (gy > mtiles) gy = mtiles;
     void* ws;
     int rc = ssdseg_partials(ctx, (size_t)gy * k * n * sizeof(float), &ws);
@@ -1874,8 +1886,6 @@ int ssdseg_pwconv_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssd
     const double cost_bytes = 4.0 * ((double)m * n + 2.0 * m * k + 2.0 * k * n);   // 8(d): read dY, read X, write dX, read W, write dW
     const double cost_flops = 4.0 * m * k * n;
     ctx->timing_view_bytes = dy->scale != nullptr ? 4.0 * m * n : 0.0;
-    const int nt = cdiv(n, 32);
-    const size_t wl = wres_enabled() ? wres_lds_bytes(n, 1) : 0;
     if (wl > 0) {
         char wbuf[64];
         snprintf(wbuf, sizeof(wbuf), "gemm_wres_kernel<1, 1, %d>", nt > 6 ? 6 : nt);   // NT > 0: fused dW

@@ -30,11 +30,14 @@ for direction in ("fwd", "bwd"):
         if workload == "backbone":
             for i, g in enumerate(step.seeds): eng.seed_output_grad(i, g)
             eng.mark_output_grads_written()
+    recs = [o.rec for o in eng.ops if hasattr(o, "rec")]            # BatchNorm records: `bwd_done` says a consumer already reduced them
     for op in ops:
         ctx.timing_reset()
-        snap = [s.gwritten for s in eng.stores]
+        snap = [(s.gwritten, s.pending) for s in eng.stores]
+        done = [r.bwd_done for r in recs]
         for r in range(REP):
-            for s, w in zip(eng.stores, snap): s.gwritten = w      # same accumulate flags on every repeat
+            for s, (w, pend) in zip(eng.stores, snap): s.gwritten, s.pending = w, pend      # same accumulate flags / deferred residuals on every repeat
+            for rec, d in zip(recs, done): rec.bwd_done = d        # ... and the same fused / separate BatchNorm-backward path
             getattr(op, direction)()
         rep = ctx.timing_report()
         for k, v in rep.items():
