@@ -160,6 +160,7 @@ class Val:
 # ====================================================================================================== ops
 class Op:
     name = ""
+    reach = frozenset()      # names of the model outputs that depend on this op (set by Engine._emit)
 
     def fwd(self):
         pass
@@ -679,7 +680,10 @@ class Engine:
         self._wt_table = None
         self._alloc_params(grad_bucket)
         self._plan_concats()
+        reach = self._outputs_reached()
+        self._cur_reach = frozenset()
         for layer in model.layers:
+            self._cur_reach = reach[id(layer)]
             self._lower(layer)
         self.output_vals = [self.vals[id(t)] for t in model.outputs]
         self.adam_step_count = 0
@@ -883,8 +887,65 @@ class Engine:
         return st
 
     def _emit(self, op: Op):
+        op.reach = self._cur_reach          # names of the model outputs that depend on this op (branch scheduling, _schedule)
         self.ops.append(op)
+        self._plans = None
         return op
+
+    # ------------------------------------------------------------------ two independent branches on two streams
+    DET_OUTPUTS = frozenset(("output-labels", "output-boxes"))      # the reference's output names (models.py:259,271)
+
+    def _outputs_reached(self) -> Dict[int, frozenset]:
+        """id(layer) -> names of the model outputs that depend on it"""
+        names = {id(t): t.layer.name for t in self.model.outputs}
+        reach: Dict[int, frozenset] = {}
+        for layer in reversed(self.model.layers):
+            r = set()
+            for t in layer.outputs:
+                if id(t) in names:
+                    r.add(names[id(t)])
+                for c in self.cons.get(id(t), []):
+                    r |= reach.get(id(c), frozenset())
+            reach[id(layer)] = frozenset(r)
+        return reach
+
+    def _schedule(self):
+        """The multi-task graph is a shared trunk (the backbone) with two independent branches: the mask branch (ASPP, decoder,
+        mask head: long kernels that fill the chip) and the detection branch (extra feature maps, eight SSDLite heads, gather,
+        softmax, detection losses: ~90 launches of 5-20 us that leave most CUs idle).  A training engine issues the detection
+        branch on the context's SIDE stream -- forward right behind the trunk, backward right at the start -- so its small
+        kernels run beside the mask branch's instead of after them.  The issue ORDER of the backward pass is unchanged (reverse
+        layer order: detection, mask, trunk), so every first-writer / accumulate decision and every summation order is the
+        same: results are bit-identical with SSDSEG_DET_SIDE=0 (everything on one stream).  Cross-stream hazards: a mask-branch
+        backward op that accumulates into a trunk tensor's gradient the detection branch wrote first (the block-13 tap feeds
+        the ASPP and the first SSD head) waits for the side stream (`join_before`); the trunk's backward joins anyway.
+        -> (trunk, detection, mask, join_before)"""
+        if not self.training or os.environ.get("SSDSEG_DET_SIDE", "1") == "0":      # (read per pass: A/B runs and tests flip it)
+            return self.ops, [], [], set()
+        if getattr(self, "_plans", None) is not None:
+            return self._plans
+        det = [op for op in self.ops if op.reach and op.reach <= self.DET_OUTPUTS]
+        mask = [op for op in self.ops if op.reach and not (op.reach & self.DET_OUTPUTS)]
+        if not det or not mask:
+            self._plans = (list(self.ops), [], [], set())
+            return self._plans
+        det_ids, mask_ids = {id(o) for o in det}, {id(o) for o in mask}
+        trunk = [op for op in self.ops if id(op) not in det_ids and id(op) not in mask_ids]
+
+        def touched(op):
+            out = set()
+            for v in vars(op).values():
+                for x in (v if isinstance(v, (list, tuple)) else (v,)):
+                    st = x.store if isinstance(x, Val) else (x if isinstance(x, Store) else None)
+                    while st is not None:
+                        out.add(id(st))
+                        st = st.parent
+            return out
+
+        det_touch = set().union(*[touched(op) for op in det]) if det else set()
+        join_before = {id(op) for op in mask if touched(op) & det_touch}
+        self._plans = (trunk, det, mask, join_before)
+        return self._plans
 
     def _dense(self, v: Val, name: str) -> Val:
         """a Val over a dense store (materialise sliced / strided inputs for kernels that need ld == c)"""
@@ -1177,8 +1238,18 @@ class Engine:
     def forward(self):
         self._sync_padded("p", to_bucket=False)          # padded copies of the weights <- bucket (no-op for most models)
         self._refresh_wt()                                # transposed copies of the pointwise kernels: one launch
-        for op in self.ops:
+        trunk, det, mask, _ = self._schedule()
+        for op in trunk:
             op.fwd()
+        if det:
+            self.ctx.side(True)              # forks behind the trunk: the detection branch runs beside the mask branch
+            for op in det:
+                op.fwd()
+            self.ctx.side(False)
+            for op in mask:
+                op.fwd()
+            if getattr(self, "_metrics", None):
+                self.ctx.join()              # the metric kernels read both branches' outputs on the main stream
         if self.training:
             self._sync_padded("p", to_bucket=True, which="state")   # moving statistics of padded BatchNorms -> bucket
 
@@ -1196,7 +1267,19 @@ class Engine:
             if s.split_parent and s.need_grad:
                 s.grad.zero_()
                 s.gwritten = True
-        for op in reversed(self.ops):
+        trunk, det, mask, join_before = self._schedule()
+        if det:
+            self.ctx.side(True)
+            for op in reversed(det):
+                op.bwd()
+            self.ctx.side(False)
+            for op in reversed(mask):
+                if id(op) in join_before:
+                    self.ctx.join()          # this op adds to a gradient the detection branch wrote first
+                    join_before = ()
+                op.bwd()
+            self.ctx.join()                  # the trunk's backward reads both branches' gradients
+        for op in reversed(trunk):
             op.bwd()
         for s in self.stores:
             s._materialise_pending()
@@ -1280,6 +1363,7 @@ class Engine:
                     det.y_labels = self.ctx.empty((b, a, labels_v.store.c))
                     det.y_boxes = self.ctx.empty((b, a, 4))
                     self.loss_ops["det"] = det
+                    self._cur_reach = self.DET_OUTPUTS
                     self._emit(det)
                 if fn is LS.confidence_loss:
                     det.w_conf = w

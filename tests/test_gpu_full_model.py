@@ -207,3 +207,41 @@ def test_fit_overlapped_upload_equals_synchronous(ctx, rng, monkeypatch):
     assert hist["1"].keys() == hist["0"].keys()
     for k in hist["1"]:
         assert hist["1"][k] == hist["0"][k], (k, hist["1"][k], hist["0"][k])
+
+
+def test_detection_branch_on_the_side_stream_is_bit_identical(ctx, rng, monkeypatch):
+    """Round 3: a training engine issues the detection branch (extra feature maps, SSD heads, detection losses) on the
+    context's side stream, beside the mask branch (Engine._schedule).  Same kernels, same backward issue order, hence the same
+    first-writer / accumulate decisions and summation orders: gradients, losses, parameters and moving statistics are the
+    same bits with everything on one stream (SSDSEG_DET_SIDE=0).  Also with metrics bound (they read both branches' outputs)."""
+    import ssdseglib
+    from ssdseglib import _engine as E
+    batch = 3
+    boxes, builder, model = build(seed=23)
+    enc, gts, targets = make_targets(rng, boxes, batch)
+    model.compile(optimizer=ssdseglib.optimizers.Adam(learning_rate=1e-3),
+                  loss={'output-mask': ssdseglib.losses.cross_entropy(classes_weights=CW), 'output-labels': ssdseglib.losses.confidence_loss,
+                        'output-boxes': ssdseglib.losses.localization_loss},
+                  metrics={'output-labels': ssdseglib.metrics.categorical_accuracy(classes_weights=(1.0, 1.0, 1.0, 1.0))})
+    eng = E.Engine(model, batch, training=True, ctx=ctx)
+    eng.configure_losses(model._compiled["loss"], model._compiled["loss_weights"])
+    eng.configure_metrics(model._compiled["metrics"])
+    trunk, det, mask, join_before = eng._schedule()
+    assert len(det) > 30 and len(mask) > 30 and len(trunk) > 100 and join_before, (len(trunk), len(det), len(mask), len(join_before))
+    assert any(op.name == "det-loss" for op in det) and all("mask" in op.name or "output-mask" in op.name for op in mask)
+    x = rng.integers(0, 256, (batch,) + SHAPE).astype(np.float32)
+    P = eng.P
+    p0, s0 = P["params"].download(), P["state"].download()
+
+    def run(split):
+        monkeypatch.setenv("SSDSEG_DET_SIDE", "1" if split else "0")
+        P["params"].upload(p0); P["state"].upload(s0)
+        P["adam_m"].zero_(); P["adam_v"].zero_(); P["step"] = 0
+        eng.train_step(x, targets, optimizer=model._compiled["optimizer"])
+        ctx.sync()
+        return P["grads"].download(), P["params"].download(), P["state"].download(), eng.losses()
+
+    a, b, c = run(True), run(False), run(True)
+    for u, v in ((a, b), (a, c)):
+        assert np.array_equal(u[0], v[0]) and np.array_equal(u[1], v[1]) and np.array_equal(u[2], v[2]) and u[3] == v[3]
+    assert np.isfinite(a[0]).all() and np.abs(a[0]).max() > 0 and all(np.isfinite(v) for v in a[3].values())
