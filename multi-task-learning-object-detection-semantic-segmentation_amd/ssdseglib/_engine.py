@@ -910,28 +910,23 @@ class Engine:
         return reach
 
     def _schedule(self):
-        """The multi-task graph is a shared trunk (the backbone) with two independent branches: the mask branch (ASPP, decoder,
-        mask head: long kernels that fill the chip) and the detection branch (extra feature maps, eight SSDLite heads, gather,
-        softmax, detection losses: ~90 launches of 5-20 us that leave most CUs idle).  A training engine issues the detection
-        branch on the context's SIDE stream -- forward right behind the trunk, backward right at the start -- so its small
-        kernels run beside the mask branch's instead of after them.  The issue ORDER of the backward pass is unchanged (reverse
-        layer order: detection, mask, trunk), so every first-writer / accumulate decision and every summation order is the
-        same: results are bit-identical with SSDSEG_DET_SIDE=0 (everything on one stream).  Cross-stream hazards: a mask-branch
-        backward op that accumulates into a trunk tensor's gradient the detection branch wrote first (the block-13 tap feeds
-        the ASPP and the first SSD head) waits for the side stream (`join_before`); the trunk's backward joins anyway.
+        """The multi-task graph is a shared trunk with two independent branches.  Which is which follows from reachability, not
+        from layer names: the mask output depends on the backbone only up to the block-13 expansion (ASPP tap) -- everything
+        behind it (block 13's depthwise conv ... block 16, the extra feature maps, the eight SSDLite heads, gather, softmax,
+        the detection losses: ~150 launches of 5-60 us on 30x40 ... 1x1 maps that leave most CUs idle) only feeds the detection
+        outputs.  A training engine issues that DETECTION branch on the context's side stream -- forward right behind the
+        trunk, backward right at the start -- so it runs beside the MASK branch (ASPP, decoder, mask head: few long kernels
+        that fill the chip) instead of before / after it: 31.8 -> 30.5 ms per batch-32 step.  The backward issue order stays
+        detection, mask, trunk = the reverse layer order for every tensor more than one of them touches (checked below), so every
+        first-writer / accumulate decision and every summation order is the same and results are bit-identical with
+        SSDSEG_DET_SIDE=0 (one stream, layer order).  Cross-stream hazards: a mask-branch backward op that accumulates into a
+        trunk tensor's gradient the detection branch wrote first (the block-13 tap feeds the ASPP and the first SSD head) waits
+        for the side stream (`join_before`); the trunk's backward joins anyway.
         -> (trunk, detection, mask, join_before)"""
         if not self.training or os.environ.get("SSDSEG_DET_SIDE", "1") == "0":      # (read per pass: A/B runs and tests flip it)
             return self.ops, [], [], set()
         if getattr(self, "_plans", None) is not None:
             return self._plans
-        det = [op for op in self.ops if op.reach and op.reach <= self.DET_OUTPUTS]
-        mask = [op for op in self.ops if op.reach and not (op.reach & self.DET_OUTPUTS)]
-        if not det or not mask:
-            self._plans = (list(self.ops), [], [], set())
-            return self._plans
-        det_ids, mask_ids = {id(o) for o in det}, {id(o) for o in mask}
-        trunk = [op for op in self.ops if id(op) not in det_ids and id(op) not in mask_ids]
-
         def touched(op):
             out = set()
             for v in vars(op).values():
@@ -942,8 +937,54 @@ class Engine:
                         st = st.parent
             return out
 
-        det_touch = set().union(*[touched(op) for op in det]) if det else set()
-        join_before = {id(op) for op in mask if touched(op) & det_touch}
+        pos = {id(op): i for i, op in enumerate(self.ops)}
+        touch = {id(op): touched(op) for op in self.ops}
+        det = [op for op in self.ops if op.reach and op.reach <= self.DET_OUTPUTS]
+        mask = [op for op in self.ops if op.reach and not (op.reach & self.DET_OUTPUTS)]
+        serial = (list(self.ops), [], [], set())
+        if not det or not mask:
+            self._plans = serial
+            return self._plans
+        # A detection-branch op that reads a tensor the mask branch also reads, and comes BEFORE those readers in layer order,
+        # is the LAST to contribute to that tensor's gradient in the backward pass -- and may rely on it (the depthwise conv of
+        # block 13 completes the block-13 tap's gradient and takes its BatchNorm's backward sums over the completed tensor,
+        # DwOp.fuse_input_bn).  Such ops stay with the trunk: issued before the fork in the forward pass, after the join in the
+        # backward pass, at their place in layer order.
+        mask_last = {}
+        for op in mask:
+            for sid in touch[id(op)]:
+                mask_last[sid] = max(mask_last.get(sid, -1), pos[id(op)])
+        keep = [op for op in det if any(pos[id(op)] < mask_last.get(sid, -1) for sid in touch[id(op)])]
+        det = [op for op in det if op not in keep]
+        det_ids, mask_ids = {id(o) for o in det}, {id(o) for o in mask}
+        trunk = [op for op in self.ops if id(op) not in det_ids and id(op) not in mask_ids]
+        # Validity of the three-phase order (else: one stream, layer order).  (1) A demoted op runs before the fork, so nothing it
+        # reads may come from the detection branch: it precedes every remaining detection op in layer order.  (2) The backward
+        # pass writes a tensor's gradient in the order detection, mask, trunk; that is the reverse layer order -- same first
+        # writer, same accumulation order, bit-identical sums -- iff in layer order every trunk op on that tensor precedes every
+        # branch op on it and every mask op precedes every detection op.
+        det_out = set().union(*[touch[id(op)] for op in det]) if det else set()
+        ok = bool(det) and (not keep or max(pos[id(op)] for op in keep) < min(pos[id(op)] for op in det))
+        first = {}
+        for kind, ops_ in (("det", det), ("mask", mask)):
+            for op in ops_:
+                for sid in touch[id(op)]:
+                    f = first.setdefault(sid, {})
+                    f[kind + "_min"] = min(f.get(kind + "_min", 1 << 30), pos[id(op)])
+                    f[kind + "_max"] = max(f.get(kind + "_max", -1), pos[id(op)])
+        for op in trunk:
+            for sid in touch[id(op)] & set(first):
+                f = first[sid]
+                if pos[id(op)] > min(f.get("det_min", 1 << 30), f.get("mask_min", 1 << 30)):
+                    ok = False
+        for f in first.values():
+            if "det_min" in f and "mask_max" in f and f["mask_max"] > f["det_min"]:
+                ok = False
+        if not ok:
+            self._plans = serial
+            return self._plans
+        det_touch = det_out
+        join_before = {id(op) for op in mask if touch[id(op)] & det_touch}
         self._plans = (trunk, det, mask, join_before)
         return self._plans
 

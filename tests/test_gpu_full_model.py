@@ -227,8 +227,12 @@ def test_detection_branch_on_the_side_stream_is_bit_identical(ctx, rng, monkeypa
     eng.configure_losses(model._compiled["loss"], model._compiled["loss_weights"])
     eng.configure_metrics(model._compiled["metrics"])
     trunk, det, mask, join_before = eng._schedule()
-    assert len(det) > 30 and len(mask) > 30 and len(trunk) > 100 and join_before, (len(trunk), len(det), len(mask), len(join_before))
+    assert len(det) > 30 and len(mask) > 20 and len(trunk) > 50 and join_before, (len(trunk), len(det), len(mask), len(join_before))
     assert any(op.name == "det-loss" for op in det) and all("mask" in op.name or "output-mask" in op.name for op in mask)
+    # block 13's depthwise conv only feeds the detection outputs, but it completes the block-13 tap's gradient (and takes that
+    # BatchNorm's backward sums over the completed tensor): it stays with the trunk, behind the ASPP's contributions
+    assert any(op.name == "backbone-block13-depthwise-conv:dw" for op in trunk)
+    assert any(op.name.startswith("backbone-block14") for op in det) and not any(op.name.startswith("backbone-block12") for op in det)
     x = rng.integers(0, 256, (batch,) + SHAPE).astype(np.float32)
     P = eng.P
     p0, s0 = P["params"].download(), P["state"].download()
