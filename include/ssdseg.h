@@ -246,6 +246,10 @@ int ssdseg_conv3x3_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const fl
 int ssdseg_conv3x3_saved_floats(int n, int h, int w, int cin, int cout, long long* floats_host);
 int ssdseg_conv3x3_fwd_saved(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const float* w, float* y, int n, int h, int wdt, int cin,
                              int cout, float* stats, float* xsaved);
+/* the same when the channels [0, c_from) of xsaved already hold the activated input (ssdseg_bilinear_fwd_padded wrote them over
+ * a border that was zero when the buffer was made): only channels [c_from, cin) of `in` are viewed and copied. */
+int ssdseg_conv3x3_fwd_saved_from(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const float* w, float* y, int n, int h,
+                                  int wdt, int cin, int cout, float* stats, float* xsaved, int c_from);
 int ssdseg_conv3x3_bwd_weight_saved(ssdseg_ctx* ctx, const float* xsaved, const float* dy, float* dw, int n, int h, int wdt, int cin,
                                     int cout);
 int ssdseg_conv3x3_bwd_data(ssdseg_ctx* ctx, const ssdseg_gview* dy, const float* w, float* dx, int ldx, int n,
@@ -302,6 +306,11 @@ int ssdseg_bilinear_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, float* 
                         int c, int fy, int fx);
 int ssdseg_bilinear_bwd(ssdseg_ctx* ctx, const float* g, int ldg, float* dx, int ldx, int n, int h, int wdt, int c,
                         int fy, int fx, int accumulate);
+/* the forward written into the INTERIOR of a bordered tensor out[n][h*fy + 2][wdt*fx + 2][ldo] (border untouched): the x4
+ * up-sampled ASPP output (blocks.py:104) lands directly in the zero-bordered input copy the decoder's 3x3 conv kernels read
+ * (blocks.py:117; ssdseg_conv3x3_fwd_saved_from), instead of in a plain concat buffer that a padding pass copies again. */
+int ssdseg_bilinear_fwd_padded(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, float* out, int ldo, int n, int h, int wdt,
+                               int c, int fy, int fx);
 
 /* ---------------------------------------------------------------- K12+K13: mask head tail
  * logits [n][h][w][c] --x(fy,fx) bilinear--> softmax -> probabilities (output-mask, blocks.py:128-130),

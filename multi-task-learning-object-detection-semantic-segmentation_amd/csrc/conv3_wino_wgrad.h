@@ -285,15 +285,18 @@ __global__ void __launch_bounds__(256) conv3_wino_wgrad_finalize_kernel(const fl
     }
 }
 
-// act(scale * x + shift) of the [n][h][w][ldx] input (first cin channels) into the zero-bordered [n][h+2][w+2][cin] copy
+// act(scale * x + shift) of the [n][h][w][ldx] input (channels c_from .. cin-1) into the zero-bordered [n][h+2][w+2][cin] copy; the
+// channels below c_from already hold their values (written there by their producer: ssdseg_bilinear_fwd_padded) over a border that
+// was zero when the buffer was made
 __global__ void __launch_bounds__(256) conv3_pad_view_kernel(const float* __restrict__ x, const float* __restrict__ cs, const float* __restrict__ ct, int act, int ldx,
-                                                             float* __restrict__ xp, int n, int h, int w, int cin) {
-    const int cv = cin >> 2;
+                                                             float* __restrict__ xp, int n, int h, int w, int cin, int c_from) {
+    const int cv = (cin - c_from) >> 2, q0 = c_from >> 2, cvall = cin >> 2;
     const long long total = (long long)n * (h + 2) * (w + 2) * cv;
     const float lo = act_lo(act), hi = act_hi(act);
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int q = (int)(i % cv);
+        const int q = q0 + (int)(i % cv);
         long long pix = i / cv;
+        const long long pixel = pix;
         const int pw = (int)(pix % (w + 2));
         pix /= (w + 2);
         const int ph = (int)(pix % (h + 2)), img = (int)(pix / (h + 2));
@@ -303,6 +306,6 @@ __global__ void __launch_bounds__(256) conv3_pad_view_kernel(const float* __rest
             const float4 s = cs != nullptr ? ld4(cs + 4 * q) : f4(1.f), tt = cs != nullptr ? ld4(ct + 4 * q) : f4(0.f);
             v = view_affine4(v, s, tt, lo, hi);
         }
-        st4(xp + i * 4, v);
+        st4(xp + (pixel * cvall + q) * 4, v);
     }
 }

@@ -1702,7 +1702,7 @@ int conv3_wino_wgrad_launch(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, con
     if (xsaved == nullptr) {
         const long long tot4 = (long long)n * (h + 2) * (w + 2) * (cin / 4);
         SSDSEG_LAUNCH(ctx, 8.0 * m * cin, 0.0, conv3_pad_view_kernel, dim3((unsigned)((tot4 + 255) / 256 < 16384 ? (tot4 + 255) / 256 : 16384)), dim3(256), 0, in->x,
-                      in->scale, in->shift, in->act, ldx, xp, n, h, w, cin);
+                      in->scale, in->shift, in->act, ldx, xp, n, h, w, cin, 0);
         SSDSEG_LAUNCH_CHECK();
     }
     static bool configured = false;   // dynamic LDS beyond 64 KiB has to be announced once
@@ -2250,7 +2250,13 @@ int ssdseg_conv3x3_saved_floats(int n, int h, int w, int cin, int cout, long lon
 
 int ssdseg_conv3x3_fwd_saved(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const float* w, float* y, int n, int h, int wdt, int cin, int cout,
                              float* stats, float* xsaved) {
+    return ssdseg_conv3x3_fwd_saved_from(ctx, in, ldx, w, y, n, h, wdt, cin, cout, stats, xsaved, 0);
+}
+
+int ssdseg_conv3x3_fwd_saved_from(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const float* w, float* y, int n, int h, int wdt, int cin,
+                                  int cout, float* stats, float* xsaved, int c_from) {
     SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(c_from >= 0 && c_from < cin && c_from % 4 == 0, 13);
     SSDSEG_ARG(in != nullptr && in->x != nullptr && ((in->scale == nullptr) == (in->shift == nullptr)), 2);
     SSDSEG_ARG(ldx >= cin && ldx % 4 == 0, 3);
     SSDSEG_ARG(w != nullptr, 4);
@@ -2260,9 +2266,9 @@ int ssdseg_conv3x3_fwd_saved(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, co
     int rc = ssdseg_conv3x3_saved_floats(n, h, wdt, cin, cout, &need);
     if (rc) return rc;
     SSDSEG_ARG(need > 0, 6);     // only for shapes ssdseg_conv3x3_saved_floats reports a size for
-    const long long tot4 = (long long)n * (h + 2) * (wdt + 2) * (cin / 4);
-    SSDSEG_LAUNCH(ctx, 8.0 * n * h * wdt * cin, 0.0, conv3_pad_view_kernel, dim3((unsigned)((tot4 + 255) / 256 < 16384 ? (tot4 + 255) / 256 : 16384)), dim3(256), 0,
-                  in->x, in->scale, in->shift, in->act, ldx, xsaved, n, h, wdt, cin);
+    const long long tot4 = (long long)n * (h + 2) * (wdt + 2) * ((cin - c_from) / 4);
+    SSDSEG_LAUNCH(ctx, 8.0 * n * h * wdt * (cin - c_from), 0.0, conv3_pad_view_kernel, dim3((unsigned)((tot4 + 255) / 256 < 16384 ? (tot4 + 255) / 256 : 16384)), dim3(256), 0,
+                  in->x, in->scale, in->shift, in->act, ldx, xsaved, n, h, wdt, cin, c_from);
     SSDSEG_LAUNCH_CHECK();
     Conv3TArgs t{};
     t.in = xsaved + ((long long)(wdt + 2) + 1) * cin;      // pixel (1, 1) of image 0 of the zero-bordered copy

@@ -124,8 +124,9 @@ __device__ __forceinline__ float lerp_weight(int dst, int i, int in_size, float 
 }
 
 __global__ void bilinear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift, int act,
-                                    int ldx, float* __restrict__ out, int ldo, int n, int h, int w, int cv, int fy, int fx) {
+                                    int ldx, float* __restrict__ out, int ldo, int n, int h, int w, int cv, int fy, int fx, int pad) {
     const int ho = h * fy, wo = w * fx;
+    const int hp = ho + 2 * pad, wp = wo + 2 * pad;       // pad = 1: the output is the interior of a bordered [n][ho+2][wo+2] tensor
     const long long total = (long long)n * ho * wo * cv;
     const bool aff = scale != nullptr;
     const float ify = 1.f / (float)fy, ifx = 1.f / (float)fx;
@@ -147,7 +148,7 @@ __global__ void bilinear_fwd_kernel(const float* __restrict__ x, const float* __
         top.x = v00.x + (v01.x - v00.x) * lx.f; top.y = v00.y + (v01.y - v00.y) * lx.f; top.z = v00.z + (v01.z - v00.z) * lx.f; top.w = v00.w + (v01.w - v00.w) * lx.f;
         bot.x = v10.x + (v11.x - v10.x) * lx.f; bot.y = v10.y + (v11.y - v10.y) * lx.f; bot.z = v10.z + (v11.z - v10.z) * lx.f; bot.w = v10.w + (v11.w - v10.w) * lx.f;
         o.x = top.x + (bot.x - top.x) * ly.f; o.y = top.y + (bot.y - top.y) * ly.f; o.z = top.z + (bot.z - top.z) * ly.f; o.w = top.w + (bot.w - top.w) * ly.f;
-        st4(out + ((img * ho + oy) * wo + ox) * ldo + c0, o);
+        st4(out + ((img * hp + oy + pad) * wp + ox + pad) * ldo + c0, o);
     }
 }
 
@@ -156,7 +157,7 @@ __global__ void bilinear_fwd_kernel(const float* __restrict__ x, const float* __
 // (and activates) once -- 9 loads per 16 outputs where the kernel above does 64 -- and every output is formed by the same
 // expression from the same operands: bit-identical.
 __global__ void __launch_bounds__(256) bilinear_fwd_x4_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
-                                                             int act, int ldx, float* __restrict__ out, int ldo, int n, int h, int w, int cv) {
+                                                             int act, int ldx, float* __restrict__ out, int ldo, int n, int h, int w, int cv, int pad) {
     const long long total = (long long)n * h * w * cv;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
@@ -182,6 +183,7 @@ __global__ void __launch_bounds__(256) bilinear_fwd_x4_kernel(const float* __res
         }
     }
     const int ho = h * 4, wo = w * 4;
+    const int hp = ho + 2 * pad, wp = wo + 2 * pad;
     Lerp lx[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) lx[j] = lerp_of(bx * 4 + j, w, 0.25f);
@@ -210,7 +212,7 @@ __global__ void __launch_bounds__(256) bilinear_fwd_x4_kernel(const float* __res
             top.x = v00.x + (v01.x - v00.x) * fx; top.y = v00.y + (v01.y - v00.y) * fx; top.z = v00.z + (v01.z - v00.z) * fx; top.w = v00.w + (v01.w - v00.w) * fx;
             bot.x = v10.x + (v11.x - v10.x) * fx; bot.y = v10.y + (v11.y - v10.y) * fx; bot.z = v10.z + (v11.z - v10.z) * fx; bot.w = v10.w + (v11.w - v10.w) * fx;
             o.x = top.x + (bot.x - top.x) * fy; o.y = top.y + (bot.y - top.y) * fy; o.z = top.z + (bot.z - top.z) * fy; o.w = top.w + (bot.w - top.w) * fy;
-            st4(out + ((img * ho + oy) * wo + bx * 4 + jx) * ldo + c0, o);
+            st4(out + ((img * hp + oy + pad) * wp + bx * 4 + jx + pad) * ldo + c0, o);
         }
     }
 }
@@ -739,8 +741,8 @@ int ssdseg_gap_bwd(ssdseg_ctx* ctx, const float* g, float* dx, int n, int hw, in
     return 0;
 }
 
-int ssdseg_bilinear_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, float* out, int ldo, int n, int h, int wdt, int c, int fy,
-                        int fx) {
+static int bilinear_fwd_impl(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, float* out, int ldo, int n, int h, int wdt, int c, int fy, int fx,
+                             int pad) {
     SSDSEG_ARG(ctx != nullptr, 1);
     SSDSEG_ARG(in != nullptr && in->x != nullptr && ((in->scale == nullptr) == (in->shift == nullptr)), 2);
     SSDSEG_ARG(ldx >= c && ldx % 4 == 0, 3);
@@ -754,14 +756,26 @@ int ssdseg_bilinear_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, float* 
     if (fy == 4 && fx == 4 && !(bl != nullptr && !strcmp(bl, "gather"))) {
         const long long threads = (long long)n * h * wdt * (c / 4);
         SSDSEG_LAUNCH(ctx, 4.0 * ((double)n * h * wdt * c + 4.0 * total), 0.0, bilinear_fwd_x4_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, in->x,
-                      in->scale, in->shift, in->act, ldx, out, ldo, n, h, wdt, c / 4);
+                      in->scale, in->shift, in->act, ldx, out, ldo, n, h, wdt, c / 4, pad);
         SSDSEG_LAUNCH_CHECK();
         return 0;
     }
     SSDSEG_LAUNCH(ctx, 4.0 * ((double)n * h * wdt * c + 4.0 * total), 0.0, bilinear_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, in->x,
-                  in->scale, in->shift, in->act, ldx, out, ldo, n, h, wdt, c / 4, fy, fx);
+                  in->scale, in->shift, in->act, ldx, out, ldo, n, h, wdt, c / 4, fy, fx, pad);
     SSDSEG_LAUNCH_CHECK();
     return 0;
+}
+
+int ssdseg_bilinear_fwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, float* out, int ldo, int n, int h, int wdt, int c, int fy,
+                        int fx) {
+    return bilinear_fwd_impl(ctx, in, ldx, out, ldo, n, h, wdt, c, fy, fx, 0);
+}
+
+// the same values written into the INTERIOR of a bordered tensor out[n][h*fy + 2][w*fx + 2][ldo] (the border is left alone): the
+// up-sampled ASPP output lands directly in the zero-bordered input copy the decoder's 3x3 conv kernels read (ssdseg_conv3x3_fwd_saved_from)
+int ssdseg_bilinear_fwd_padded(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, float* out, int ldo, int n, int h, int wdt, int c, int fy,
+                               int fx) {
+    return bilinear_fwd_impl(ctx, in, ldx, out, ldo, n, h, wdt, c, fy, fx, 1);
 }
 
 int ssdseg_bilinear_bwd(ssdseg_ctx* ctx, const float* g, int ldg, float* dx, int ldx, int n, int h, int wdt, int c, int fy, int fx,

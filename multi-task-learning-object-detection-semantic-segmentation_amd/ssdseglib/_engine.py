@@ -295,13 +295,27 @@ class Conv3Op(Op):
             need = C.c_longlong()
             H._check(eng.ctx.lib.ssdseg_conv3x3_saved_floats(s.n, s.h, s.w, s.c, out.c, C.byref(need)), "ssdseg_conv3x3_saved_floats")
             if need.value > 0:
-                self.xsaved = eng.ctx.empty(need.value)
+                self.xsaved = eng.ctx.zeros(need.value)       # (the border stays zero for the life of the buffer)
+        # The input of the DeepLabV3+ decoder conv is Concatenate(up-sampled ASPP output, backbone branch) (blocks.py:104-113).  The
+        # up-sampling writes final (already activated) values into channels [0, c) of the concat buffer, which the saved-input
+        # forward then copies into the zero-bordered buffer.  Nothing else reads those channels of the plain concat buffer, so the
+        # up-sampling writes them into the bordered buffer directly and the copy shrinks to the other branch's channels.
+        self.saved_from = 0
+        if self.xsaved is not None and s.ld == s.c:
+            up = [op for op in eng.ops if isinstance(op, BilinearOp) and op.out.parent is s and op.out.coff == 0 and op.out.ld == s.c
+                  and op.out.h == s.h and op.out.w == s.w]
+            users = [op for op in eng.ops if any((getattr(v, "store", v) is s) for v in vars(op).values())]
+            sole = len(eng.cons.get(id(layer.inbound[0]), [])) == 1 and id(layer.inbound[0]) not in {id(t) for t in eng.model.outputs}
+            if len(up) == 1 and not users and sole:
+                up[0].padded_out = (self.xsaved, s.c)
+                self.saved_from = up[0].out.c
 
     def fwd(self):
         s = self.inp.store
         if self.xsaved is not None:
-            self.e.ctx.call("ssdseg_conv3x3_fwd_saved", self.inp.view(), s.ld, self.w, self.out.buf, s.n, s.h, s.w, s.c, self.out.c, self.out.stats,
-                            self.xsaved)
+            c_from = self.saved_from if os.environ.get("SSDSEG_CONV3_PADFUSE", "1") != "0" else 0
+            self.e.ctx.call("ssdseg_conv3x3_fwd_saved_from", self.inp.view(), s.ld, self.w, self.out.buf, s.n, s.h, s.w, s.c, self.out.c,
+                            self.out.stats, self.xsaved, c_from)
             return
         self.e.ctx.call("ssdseg_conv3x3_fwd", self.inp.view(), s.ld, self.w, self.out.buf, s.n, s.h, s.w, s.c, self.out.c, self.out.stats)
 
@@ -535,8 +549,16 @@ class BilinearOp(Op):
     def __init__(self, eng, inp: Val, out: Store, fy: int, fx: int, name):
         self.e, self.inp, self.out, self.fy, self.fx, self.name = eng, inp, out, fy, fx, name
 
+    # set by a Conv3Op that keeps a zero-bordered copy of its (concatenated) input: (buffer, row stride in floats) -- this op's
+    # output then goes straight into the interior of that copy and the plain concat slice is not written (Conv3Op.__init__)
+    padded_out = None
+
     def fwd(self):
         s = self.inp.store
+        if self.padded_out is not None and os.environ.get("SSDSEG_CONV3_PADFUSE", "1") != "0":
+            buf, ld = self.padded_out
+            self.e.ctx.call("ssdseg_bilinear_fwd_padded", self.inp.view(), s.ld, buf, ld, s.n, s.h, s.w, s.c, self.fy, self.fx)
+            return
         self.e.ctx.call("ssdseg_bilinear_fwd", self.inp.view(), s.ld, self.out.buf, self.out.ld, s.n, s.h, s.w, s.c, self.fy, self.fx)
 
     def bwd(self):

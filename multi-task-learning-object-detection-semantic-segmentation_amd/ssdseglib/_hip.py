@@ -96,6 +96,7 @@ _SIGNATURES = {
     "ssdseg_conv3x3_fwd": [_vp, _VP, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "ssdseg_conv3x3_saved_floats": [_i, _i, _i, _i, _i, C.POINTER(C.c_longlong)],
     "ssdseg_conv3x3_fwd_saved": [_vp, _VP, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "ssdseg_conv3x3_fwd_saved_from": [_vp, _VP, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i],
     "ssdseg_conv3x3_bwd_weight_saved": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i],
     "ssdseg_conv3x3_bwd_data": [_vp, _GP, _vp, _vp, _i, _i, _i, _i, _i, _i, _i],
     "ssdseg_conv3x3_bwd_data_bn": [_vp, _VP, _GP, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -110,6 +111,7 @@ _SIGNATURES = {
     "ssdseg_gap_fwd": [_vp, _VP, _vp, _i, _i, _i],
     "ssdseg_gap_bwd": [_vp, _vp, _vp, _i, _i, _i, _i],
     "ssdseg_bilinear_fwd": [_vp, _VP, _i, _vp, _i, _i, _i, _i, _i, _i, _i],
+    "ssdseg_bilinear_fwd_padded": [_vp, _VP, _i, _vp, _i, _i, _i, _i, _i, _i, _i],
     "ssdseg_bilinear_bwd": [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i],
     "ssdseg_mask_head_fwd": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, C.POINTER(_f), _vp, _vp],
     "ssdseg_mask_head_bwd": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, C.POINTER(_f), _f, _vp],

@@ -13,6 +13,8 @@ Tolerances as in test_gpu_conv_ops.py (2e-5 of the tensor's magnitude for single
 The last test is one whole batch-32 480x640 train step with size-independent properties: everything finite, two steps from the
 same state bit-identical, encoder output and hard-negative mask equal to the oracle's on the same device tensors.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -395,6 +397,20 @@ def test_full_train_step_batch32_480x640_properties(ctx, workload):
 
     g1, p1, s1, l1 = run()
     g2, p2, s2, l2 = run()
+    if workload == "full":
+        # round 3: the up-sampled ASPP output is written straight into the zero-bordered input copy of the decoder conv
+        # (ssdseg_bilinear_fwd_padded + ssdseg_conv3x3_fwd_saved_from); with the padding pass over all 304 channels instead
+        # (SSDSEG_CONV3_PADFUSE=0) the step is the same bits -- and so it is on one stream (SSDSEG_DET_SIDE=0)
+        from ssdseglib import _engine as E
+        conv = next(op for op in eng.ops if isinstance(op, E.Conv3Op) and op.xsaved is not None)
+        assert conv.saved_from == 256 and any(isinstance(op, E.BilinearOp) and op.padded_out is not None for op in eng.ops)
+        for var in ("SSDSEG_CONV3_PADFUSE", "SSDSEG_DET_SIDE"):
+            os.environ[var] = "0"
+            try:
+                g3, p3, s3, l3 = run()
+            finally:
+                del os.environ[var]
+            assert np.array_equal(g1, g3) and np.array_equal(p1, p3) and np.array_equal(s1, s3) and l1 == l3, var
     assert np.isfinite(g1).all() and np.isfinite(p1).all() and np.isfinite(s1).all()
     if workload == "shufflenet":
         # quirk Q1 to the letter: ReLU(max_value=0.0) in every head block zeroes their activations AND their derivative, so every

@@ -192,6 +192,26 @@ def test_bilinear(ctx, rng, monkeypatch, n, h, w, c, fy, fx):
     assert np.all(got[:, :4] == 0) and np.all(got[:, 4 + c:] == 0)
 
 
+@pytest.mark.parametrize("n,h,w,c,f,ld", [(2, 6, 8, 8, 4, 8), (3, 5, 7, 12, 4, 20), (2, 9, 4, 8, 2, 12)])
+def test_bilinear_fwd_padded(ctx, rng, n, h, w, c, f, ld):
+    """the up-sampling written into the interior of a bordered tensor == the plain up-sampling, bit for bit; border and the
+    channels beyond c untouched (x4 tile kernel and the general kernel)"""
+    from ssdseglib import _hip as H
+    x = rng.normal(0, 1, (n, h, w, c)).astype(np.float32)
+    sc, sh = rng.uniform(0.5, 1.5, c).astype(np.float32), rng.normal(0, 0.3, c).astype(np.float32)
+    v = H.view(ctx.array(x), ctx.array(sc), ctx.array(sh), O.ACT_RELU6)
+    plain = ctx.empty((n, h * f, w * f, c))
+    ctx.call("ssdseg_bilinear_fwd", v, c, plain, c, n, h, w, c, f, f)
+    init = rng.normal(0, 1, (n, h * f + 2, w * f + 2, ld)).astype(np.float32)
+    padded = ctx.array(init)
+    ctx.call("ssdseg_bilinear_fwd_padded", v, c, padded, ld, n, h, w, c, f, f)
+    got = padded.download()
+    assert np.array_equal(got[:, 1:-1, 1:-1, :c], plain.download())
+    want = init.copy()
+    want[:, 1:-1, 1:-1, :c] = got[:, 1:-1, 1:-1, :c]
+    assert np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("n,h,w", [(2, 12, 16), (1, 17, 35), (3, 5, 3)])     # whole 16x16 tiles; ragged tiles; smaller than one tile
 @pytest.mark.parametrize("f", [4, 8])
 def test_mask_head(ctx, rng, monkeypatch, n, h, w, f):
