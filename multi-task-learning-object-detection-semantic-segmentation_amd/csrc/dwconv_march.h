@@ -236,6 +236,9 @@ inline void march_split(int c, int wstrips, int* cb_out, int* spb_out, int* cchu
     static const int env_mt = getenv("SSDSEG_MARCH_MAXT") ? atoi(getenv("SSDSEG_MARCH_MAXT")) : 0;
     const int maxt = (env_mt >= 64 && env_mt <= MARCH_MAX_THREADS) ? env_mt : 256;   // 512-thread blocks measured 3-5 % slower
     int unit = env_cb > 0 ? env_cb : 64;
+    // (c = 144 -- blocks 2 / 3 at 120 x 160 -- runs as ONE 144-channel chunk: one strip of 2.25 waves per block.  Round 3 tried three
+    // 48-channel chunks x five strips (full waves, shared halos): block-2 backward 326 -> 420 us, forward 190 -> 216 us -- 192-byte
+    // channel segments are not line-aligned and every pixel row is then walked by three blocks.  Not kept.)
     int cb, cchunks;
     if (env_cb >= 0 && c > unit && c % unit == 0) { cb = unit; cchunks = c / unit; }
     else { cchunks = cdiv(c, 256); cb = cdiv(c, cchunks); }

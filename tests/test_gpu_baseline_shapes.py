@@ -189,6 +189,7 @@ DW_BASELINE = [
     (32, 240, 320, 96, 2),   # block-1 depthwise, the largest stride-2 layer (1180 MB forward)
     (32, 240, 320, 32, 1),   # block-0 depthwise
     (32, 120, 160, 256, 1),  # decoder sepconv depthwise (1259 MB forward)
+    (32, 120, 160, 144, 1),  # block-2 depthwise: 144 channels = three 48-channel chunks x five strips per block (round 3)
     (32, 120, 160, 144, 2),  # block-3 depthwise
     (32, 30, 40, 576, 1),    # block-11/12 and the SSD head depthwise convs
 ]
