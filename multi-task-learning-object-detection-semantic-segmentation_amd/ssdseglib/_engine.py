@@ -981,12 +981,12 @@ class Engine:
         det_ids, mask_ids = {id(o) for o in det}, {id(o) for o in mask}
         trunk = [op for op in self.ops if id(op) not in det_ids and id(op) not in mask_ids]
         # Validity of the three-phase order (else: one stream, layer order).  (1) A demoted op runs before the fork, so nothing it
-        # reads may come from the detection branch: it precedes every remaining detection op in layer order.  (2) The backward
+        # reads may come from the detection branch: no detection op ahead of it in layer order touches a tensor it touches.  (2) The backward
         # pass writes a tensor's gradient in the order detection, mask, trunk; that is the reverse layer order -- same first
         # writer, same accumulation order, bit-identical sums -- iff in layer order every trunk op on that tensor precedes every
         # branch op on it and every mask op precedes every detection op.
         det_out = set().union(*[touch[id(op)] for op in det]) if det else set()
-        ok = bool(det) and (not keep or max(pos[id(op)] for op in keep) < min(pos[id(op)] for op in det))
+        ok = bool(det) and not any(touch[id(k)] & touch[id(d)] for k in keep for d in det if pos[id(d)] < pos[id(k)])
         first = {}
         for kind, ops_ in (("det", det), ("mask", mask)):
             for op in ops_:

@@ -398,13 +398,16 @@ def test_full_train_step_batch32_480x640_properties(ctx, workload):
 
     g1, p1, s1, l1 = run()
     g2, p2, s2, l2 = run()
-    if workload == "full":
+    if workload != "shufflenet":
         # round 3: the up-sampled ASPP output is written straight into the zero-bordered input copy of the decoder conv
-        # (ssdseg_bilinear_fwd_padded + ssdseg_conv3x3_fwd_saved_from); with the padding pass over all 304 channels instead
-        # (SSDSEG_CONV3_PADFUSE=0) the step is the same bits -- and so it is on one stream (SSDSEG_DET_SIDE=0)
+        # (ssdseg_bilinear_fwd_padded + ssdseg_conv3x3_fwd_saved_from; x4 tile kernel for MobileNetV2, the general kernel for
+        # ShuffleNetV2's x2); with the padding pass over all 304 channels instead (SSDSEG_CONV3_PADFUSE=0) the step is the same
+        # bits -- and so it is with the detection branch on the main stream, in layer order (SSDSEG_DET_SIDE=0)
         from ssdseglib import _engine as E
         conv = next(op for op in eng.ops if isinstance(op, E.Conv3Op) and op.xsaved is not None)
         assert conv.saved_from == 256 and any(isinstance(op, E.BilinearOp) and op.padded_out is not None for op in eng.ops)
+        trunk, det, mask, join_before = eng._schedule()
+        assert len(det) > 50 and len(mask) > 20 and join_before, (len(trunk), len(det), len(mask))
         for var in ("SSDSEG_CONV3_PADFUSE", "SSDSEG_DET_SIDE"):
             os.environ[var] = "0"
             try:
