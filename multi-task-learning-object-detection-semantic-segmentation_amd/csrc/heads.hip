@@ -250,6 +250,71 @@ __global__ void bilinear_bwd_kernel(const float* __restrict__ g, int ldg, float*
     }
 }
 
+// x4 in both directions (the gradient of the decoder's up-sampled ASPP output, 614,400 x 256 -> 38,400 x 256 at batch 32): a thread
+// owns a 2 x 2 block of INPUT pixels and one 4-channel vector.  The four pixels' supports (8 x 8 outputs each) overlap: their union
+// is 12 x 12 outputs, every one of which is loaded ONCE and added to the up to four pixels it belongs to -- 36 loads per input
+// pixel where the gather kernel above does 64 behind two lerp_weight evaluations each; the weights of the 12 rows / columns are
+// formed once per thread by the same lerp_weight (borders and clamping included).  Fixed summation order (rows, then columns).
+__global__ void __launch_bounds__(256) bilinear_bwd_x4_kernel(const float* __restrict__ g, int ldg, float* __restrict__ dx, int ldx, int n, int h, int w,
+                                                             int cv, int accumulate) {
+    const int hb = (h + 1) >> 1, wb = (w + 1) >> 1, ho = h * 4, wo = w * 4;
+    const long long total = (long long)n * hb * wb * cv;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c0 = (int)(i % cv) * 4;
+    long long r = i / cv;
+    const int bx = (int)(r % wb); r /= wb;
+    const int by = (int)(r % hb);
+    const long long img = r / hb;
+    const int iy0 = 2 * by, ix0 = 2 * bx;
+    const int oy0 = 4 * iy0 - 2, ox0 = 4 * ix0 - 2;          // first output row / column of the union window (may be < 0)
+    float wy[12][2], wx[12][2];
+#pragma unroll
+    for (int k = 0; k < 12; ++k)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int oy = oy0 + k, ox = ox0 + k;
+            wy[k][a] = (oy >= 0 && oy < ho && iy0 + a < h) ? lerp_weight(oy, iy0 + a, h, 0.25f) : 0.f;
+            wx[k][a] = (ox >= 0 && ox < wo && ix0 + a < w) ? lerp_weight(ox, ix0 + a, w, 0.25f) : 0.f;
+        }
+    float4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f4(0.f);
+    const float* base = g + img * ho * wo * (long long)ldg + c0;
+#pragma unroll 2
+    for (int ky = 0; ky < 12; ++ky) {
+        const int oy = oy0 + ky;
+        if (oy < 0 || oy >= ho) continue;
+        const float* row = base + (long long)oy * wo * ldg;
+        float4 v[12];
+#pragma unroll
+        for (int kx = 0; kx < 12; ++kx) {
+            int ox = ox0 + kx;
+            ox = ox < 0 ? 0 : (ox > wo - 1 ? wo - 1 : ox);      // (clamped columns carry weight 0)
+            v[kx] = ld4(row + (long long)ox * ldg);
+        }
+#pragma unroll
+        for (int kx = 0; kx < 12; ++kx)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) axpy4(acc[a][b], wy[ky][a] * wx[kx][b], v[kx]);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            if (iy0 + a < h && ix0 + b < w) {
+                float* p = dx + ((img * h + iy0 + a) * w + ix0 + b) * (long long)ldx + c0;
+                float4 o = acc[a][b];
+                if (accumulate) add4(o, ld4(p));
+                st4(p, o);
+            }
+        }
+}
+
 // ------------------------------------------------------------------------------------------------ mask head (4 classes)
 constexpr float KEPS = 1e-7f;  // tf.keras.backend.epsilon()
 
@@ -791,6 +856,14 @@ int ssdseg_bilinear_bwd(ssdseg_ctx* ctx, const float* g, int ldg, float* dx, int
     if (h == 1 && wdt == 1)   // a 1x1 source feeds every output pixel with weight 1 (the ASPP pooling branch): a plain pixel sum
         return pixel_sum(ctx, g, ldg, nullptr, nullptr, SSDSEG_ACT_NONE, dx, ldx, n, fy * fx, c, 1.f, accumulate,
                          4.0 * ((double)n * c * (1 + fy * fx)));
+    const char* bl = getenv("SSDSEG_BILINEAR");       // "gather": the general kernel (A/B runs, parity tests)
+    if (fy == 4 && fx == 4 && !(bl != nullptr && !strcmp(bl, "gather"))) {
+        const long long threads = (long long)n * ((h + 1) / 2) * ((wdt + 1) / 2) * (c / 4);
+        SSDSEG_LAUNCH(ctx, 4.0 * ((double)n * h * wdt * c * (1 + fy * fx)), 0.0, bilinear_bwd_x4_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, g,
+                      ldg, dx, ldx, n, h, wdt, c / 4, accumulate);
+        SSDSEG_LAUNCH_CHECK();
+        return 0;
+    }
     const long long total = (long long)n * h * wdt * (c / 4);
     SSDSEG_LAUNCH(ctx, 4.0 * ((double)n * h * wdt * c * (1 + fy * fx)), 0.0, bilinear_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, g, ldg,
                   dx, ldx, n, h, wdt, c / 4, fy, fx, accumulate);

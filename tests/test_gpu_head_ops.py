@@ -150,7 +150,8 @@ def test_gap(ctx, rng):
     assert rel_err(dx.download(), O.gap_bwd(g, h, w)) < 1e-6
 
 
-@pytest.mark.parametrize("n,h,w,c,fy,fx", [(2, 6, 8, 16, 4, 4), (2, 1, 1, 256, 30, 40), (1, 5, 7, 8, 2, 8), (1, 3, 3, 4, 1, 1), (3, 2, 1, 72, 4, 4)])
+@pytest.mark.parametrize("n,h,w,c,fy,fx", [(2, 6, 8, 16, 4, 4), (2, 1, 1, 256, 30, 40), (1, 5, 7, 8, 2, 8), (1, 3, 3, 4, 1, 1), (3, 2, 1, 72, 4, 4),
+                                             (2, 5, 7, 8, 4, 4), (1, 30, 40, 16, 4, 4)])
 def test_bilinear(ctx, rng, monkeypatch, n, h, w, c, fy, fx):
     from ssdseglib import _hip as H
     if fy == 4 and fx == 4:
@@ -177,6 +178,14 @@ def test_bilinear(ctx, rng, monkeypatch, n, h, w, c, fy, fx):
     dx = ctx.empty((n, h, w, c))
     ctx.call("ssdseg_bilinear_bwd", ctx.array(g), c, dx, c, n, h, w, c, fy, fx, 0)
     assert rel_err(dx.download(), dx_ref) < 1e-5
+    if fy == 4 and fx == 4:
+        # the x4 backward kernel (a 2x2 block of input pixels per thread, the 12x12 union window loaded once; odd sizes: partial
+        # blocks) against the general gather kernel: same terms, another summation order
+        dg = ctx.empty((n, h, w, c))
+        monkeypatch.setenv("SSDSEG_BILINEAR", "gather")
+        ctx.call("ssdseg_bilinear_bwd", ctx.array(g), c, dg, c, n, h, w, c, fy, fx, 0)
+        monkeypatch.delenv("SSDSEG_BILINEAR")
+        assert rel_err(dg.download(), dx_ref) < 1e-5 and rel_err(dx.download(), dg.download()) < 2e-6
     base = rng.normal(0, 1, (n, h, w, c)).astype(np.float32)
     dx.upload(base)
     ctx.call("ssdseg_bilinear_bwd", ctx.array(g), c, dx, c, n, h, w, c, fy, fx, 1)
