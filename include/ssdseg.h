@@ -89,6 +89,11 @@ int ssdseg_ctx_join(ssdseg_ctx* ctx);
 /* on != 0: the launches that follow go to the side stream (after everything queued so far); on == 0: back to the ctx stream.
  * For callers that issue a weight-gradient entry point themselves (ssdseg_pwconv_bwd does this internally). */
 int ssdseg_ctx_side(ssdseg_ctx* ctx, int on);
+/* ssdseg_ctx_side_mark: remembers the current end of the side stream; ssdseg_ctx_side_wait_mark: the ctx stream waits for that point
+ * -- and only for it: side-stream work queued after the mark keeps running beside the ctx stream (a join would wait for it too).
+ * Used by the Python engine between the detection branch (side stream) and the layers that need its gradients. */
+int ssdseg_ctx_side_mark(ssdseg_ctx* ctx);
+int ssdseg_ctx_side_wait_mark(ssdseg_ctx* ctx);
 /* enabled == 0: everything on the ctx stream from now on (used by bench.py to time a kernel without a co-running neighbour);
  * enabled != 0: side stream back on (if the ctx has one). */
 int ssdseg_ctx_side_enable(ssdseg_ctx* ctx, int enabled);

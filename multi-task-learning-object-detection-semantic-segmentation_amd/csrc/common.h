@@ -28,6 +28,8 @@ struct ssdseg_ctx {
     // called by every entry point that synchronises, copies or reads gradients.
     hipStream_t side_stream;
     hipEvent_t ev_fork, ev_join;
+    hipEvent_t ev_mark;   // ssdseg_ctx_side_mark / _wait_mark: a point on the side stream the main stream can wait for without joining it
+    bool mark_set;
     void* side_workspace;
     size_t side_workspace_bytes;
     bool side_ok, side_on, side_pending;

@@ -214,6 +214,8 @@ int ssdseg_ctx_create(int device, void* stream, ssdseg_ctx** out_host) {
     c->side_workspace = nullptr;
     c->side_workspace_bytes = 0;
     c->side_ok = c->side_on = c->side_pending = false;
+    c->ev_mark = nullptr;
+    c->mark_set = false;
     c->copy_stream = nullptr;
     c->ev_copy_fork = c->ev_copy_join = nullptr;
     c->comm = nullptr;
@@ -292,6 +294,7 @@ int ssdseg_ctx_destroy(ssdseg_ctx* ctx) {
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->ev_mark) (void)hipEventDestroy(ctx->ev_mark);
     if (ctx->copy_stream) {
         (void)hipStreamSynchronize(ctx->copy_stream);
         (void)hipStreamDestroy(ctx->copy_stream);
@@ -314,6 +317,28 @@ int ssdseg_ctx_sync(ssdseg_ctx* ctx) {
 int ssdseg_ctx_join(ssdseg_ctx* ctx) {
     SSDSEG_ARG(ctx != nullptr, 1);
     return ssdseg_join(ctx);
+}
+
+// A point on the side stream: everything queued there so far.  ssdseg_ctx_side_wait_mark makes the MAIN stream wait for that point
+// only -- not for side-stream work queued after it (a full join would also wait for the weight gradients that were queued behind
+// the detection branch).  No-ops without a side stream.
+int ssdseg_ctx_side_mark(ssdseg_ctx* ctx) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    if (ctx->side_on) ssdseg_side_end(ctx);
+    ctx->mark_set = false;
+    if (!ctx->side_ok) return 0;
+    if (ctx->ev_mark == nullptr) SSDSEG_HIP(hipEventCreateWithFlags(&ctx->ev_mark, hipEventDisableTiming));
+    SSDSEG_HIP(hipEventRecord(ctx->ev_mark, ctx->side_stream));
+    ctx->mark_set = true;
+    return 0;
+}
+
+int ssdseg_ctx_side_wait_mark(ssdseg_ctx* ctx) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(!ctx->side_on, 1);
+    if (!ctx->mark_set) return 0;
+    SSDSEG_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_mark, 0));
+    return 0;
 }
 
 int ssdseg_ctx_side_enable(ssdseg_ctx* ctx, int enabled) {

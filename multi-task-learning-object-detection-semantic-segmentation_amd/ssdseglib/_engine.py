@@ -1336,12 +1336,16 @@ class Engine:
             for op in reversed(det):
                 op.bwd()
             self.ctx.side(False)
+            # the main stream has to wait for the END OF THE DETECTION BRANCH twice -- not for the side stream as a whole, which by
+            # then also carries the mask branch's weight gradients, queued behind it (a join there stalled the main stream for them)
+            wait = self.ctx.join if os.environ.get("SSDSEG_DET_SIDE") == "join" else self.ctx.side_wait_mark      # (A/B: full joins)
+            self.ctx.side_mark()
             for op in reversed(mask):
                 if id(op) in join_before:
-                    self.ctx.join()          # this op adds to a gradient the detection branch wrote first
+                    wait()                         # this op adds to a gradient the detection branch wrote first
                     join_before = ()
                 op.bwd()
-            self.ctx.join()                  # the trunk's backward reads both branches' gradients
+            wait()                                 # the trunk's backward reads both branches' gradients
         for op in reversed(trunk):
             op.bwd()
         for s in self.stores:

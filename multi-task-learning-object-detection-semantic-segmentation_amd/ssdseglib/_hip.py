@@ -46,6 +46,8 @@ _SIGNATURES = {
     "ssdseg_ctx_join": [_vp],
     "ssdseg_ctx_side": [_vp, _i],
     "ssdseg_ctx_side_enable": [_vp, _i],
+    "ssdseg_ctx_side_mark": [_vp],
+    "ssdseg_ctx_side_wait_mark": [_vp],
     "ssdseg_colsum_defer": [_vp, _i],
     "ssdseg_ctx_reserve": [_vp, _sz],
     "ssdseg_ctx_device_name": [_vp, C.c_char_p, _sz],
@@ -353,6 +355,14 @@ class Context:
     def side(self, on: bool):
         """route the following launches to the side stream (weight gradients) / back to the ctx stream"""
         _check(self.lib.ssdseg_ctx_side(self.handle, 1 if on else 0), "ssdseg_ctx_side")
+
+    def side_mark(self):
+        """remember the current end of the side stream (include/ssdseg.h)"""
+        _check(self.lib.ssdseg_ctx_side_mark(self.handle), "ssdseg_ctx_side_mark")
+
+    def side_wait_mark(self):
+        """the ctx stream waits for the marked point of the side stream -- not for what was queued there later"""
+        _check(self.lib.ssdseg_ctx_side_wait_mark(self.handle), "ssdseg_ctx_side_wait_mark")
 
     def side_enable(self, enabled: bool):
         _check(self.lib.ssdseg_ctx_side_enable(self.handle, 1 if enabled else 0), "ssdseg_ctx_side_enable")
