@@ -241,7 +241,11 @@ int ssdseg_ctx_create(int device, void* stream, ssdseg_ctx** out_host) {
     if (!(noside && noside[0] == '1')) {
         int plo = 0, phi = 0;
         (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
-        if (hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, plo) == hipSuccess &&
+        // SSDSEG_SIDE_PRIORITY=high|low (A/B; read when the context is made).  Default LOW: the side stream fills what the main
+        // stream leaves.
+        const char* sp = getenv("SSDSEG_SIDE_PRIORITY");
+        const int sprio = (sp != nullptr && !strcmp(sp, "high")) ? phi : plo;
+        if (hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, sprio) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess)
             c->side_ok = true;
