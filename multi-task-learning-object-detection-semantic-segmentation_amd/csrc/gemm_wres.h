@@ -10,12 +10,17 @@
 //   MODE 0  y = act(s*x + t) * W            (+ BN statistics of y)
 //   MODE 1  dx = dy * W^T (+ residual, + accumulate), dy formed from (g, y) on the way in
 //   NT > 0  (MODE 1, WN 1) additionally dW = a^T * dy: one 32x32 accumulator tile per 32-column chunk of dy.
+//   RC      (NT > 0, round 3) the raw forward output y of the gradient view is RECOMPUTED, not read: this layer's y is x * W with
+//           the narrow x tile (<= 32 channels) and the resident weights both at hand, so the 6x-wide y tensor -- 43 % of the
+//           kernel's HBM traffic -- is replaced by 8-16 MFMAs per chunk on matrix pipes that are two-thirds idle here.  The
+//           recomputed tile goes through the wave's staging slab once (accumulator layout -> row layout) to meet g.
 #pragma once
 
-template <int WN, int MODE, int NT>
+template <int WN, int MODE, int NT, int RC = 0>
 __global__ void __launch_bounds__(256, 2) gemm_wres_kernel(RowAArgs p) {   // two blocks per CU: see rowa_min_waves
     constexpr bool FUSEW = NT > 0;
     static_assert(!FUSEW || (MODE == 1 && WN == 1), "fused dW only for backward-data with one column tile");
+    static_assert(!RC || FUSEW, "recomputing y needs the input tile of the fused form");
     constexpr int BN = 32 * WN;
     constexpr int BS = BN + 1;
     extern __shared__ float smem[];
@@ -26,6 +31,7 @@ __global__ void __launch_bounds__(256, 2) gemm_wres_kernel(RowAArgs p) {   // tw
     float* Ws = smem;                             // [RP][BS] resident weights (zero padded)
     float* Cs = Ws + RP * BS;                     // [4][RP] view coefficients of the streamed operand (s, t, k1, k0)
     float* As = Cs + 4 * RP + wave * (32 * AS);   // this wave's [32][AS] staging slab
+    float* Xs = Cs + 4 * RP + 4 * (32 * AS) + wave * (32 * AS);   // RC: this wave's activated input tile [32][AS] (columns >= J zero)
     const int j0 = blockIdx.x * BN;
     const bool affine = p.cs != nullptr;
 
@@ -59,7 +65,7 @@ __global__ void __launch_bounds__(256, 2) gemm_wres_kernel(RowAArgs p) {   // tw
     const int tiles = (p.I + 31) / 32;
     const int tstride = gridDim.y * 4;
 
-    float4 sg[4], sy[MODE == 1 ? 4 : 1];   // raw loads of the step in flight
+    float4 sg[4], sy[(MODE == 1 && !RC) ? 4 : 1];   // raw loads of the step in flight
     unsigned sok = 0;
     auto issue = [&](int mt, int kt) {
         const int r = kt * BK + a_c4 * 4;
@@ -70,7 +76,7 @@ __global__ void __launch_bounds__(256, 2) gemm_wres_kernel(RowAArgs p) {   // tw
             const bool ok = r < p.R && m < p.I;
             const long long off = ok ? (long long)m * p.lda + r : 0;
             sg[i] = ld4(p.a0 + off);
-            if (MODE == 1) sy[i] = ld4(ya + off);
+            if (MODE == 1 && !RC) sy[i] = ld4(ya + off);
             sok |= (ok ? 1u : 0u) << i;
         }
     };
@@ -83,6 +89,7 @@ __global__ void __launch_bounds__(256, 2) gemm_wres_kernel(RowAArgs p) {   // tw
         for (int i = 0; i < 4; ++i) {
             float4 v;
             if (MODE == 0) v = view_affine4(sg[i], cs, ct, alo, ahi);
+            else if (RC) v = gview_apply4(sg[i], ld4(As + (a_r + 8 * i) * AS + a_c4 * 4), cs, ct, ck1, ck0, gact);   // y: recomputed, in the slab
             else v = gview_apply4(sg[i], sy[i], cs, ct, ck1, ck0, gact);
             st4(As + (a_r + 8 * i) * AS + a_c4 * 4, ((sok >> i) & 1u) ? v : f4(0.f));
         }
@@ -113,6 +120,7 @@ __global__ void __launch_bounds__(256, 2) gemm_wres_kernel(RowAArgs p) {   // tw
                 const bool ok = jok && m < p.I;
                 const float v = p.xw[ok ? (long long)m * p.ldxw + li : 0];
                 xop[s] = ok ? fminf(fmaxf(fmaf(xs, v, xt), xlo), xhi) : 0.f;
+                if (RC) Xs[(2 * s + hh) * AS + li] = xop[s];      // [row][channel]: the A operand of y = x * W reads rows
             }
         }
         f32x16 acc[WN];
@@ -122,6 +130,30 @@ __global__ void __launch_bounds__(256, 2) gemm_wres_kernel(RowAArgs p) {   // tw
             for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
 
         auto kstep = [&](int kt, f32x16& wtile) {
+            if (RC) {
+                // y[m0 + row][32 kt + col] = sum_j a[row][j] W[j][col]: A = the input tile (row li, k-slots 8 kk + jj | + 4 per half-wave,
+                // as everywhere in this file), B = the resident weights Ws[col][j]; <= 16 MFMAs (J <= 32).  Then accumulator layout
+                // (column = lane & 31, rows (e & 3) + 8 (e >> 2) + 4 hh) -> the slab's [row][col], where commit() picks it up.
+                f32x16 yacc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) yacc[e] = 0.f;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // Xs written (first chunk) / slab reads of the last chunk done
+                __builtin_amdgcn_wave_barrier();
+                const float* xrow = Xs + li * AS + 4 * hh;
+                const float* wcol = Ws + (kt * BK + li) * BS + 4 * hh;
+                const int jsteps = (p.J + 7) >> 3;
+                for (int kk = 0; kk < jsteps; ++kk) {
+                    const float4 a4 = ld4(xrow + kk * 8);
+                    yacc = mfma32(a4.x, wcol[kk * 8 + 0], yacc);
+                    yacc = mfma32(a4.y, wcol[kk * 8 + 1], yacc);
+                    yacc = mfma32(a4.z, wcol[kk * 8 + 2], yacc);
+                    yacc = mfma32(a4.w, wcol[kk * 8 + 3], yacc);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) As[((e & 3) + 8 * (e >> 2) + 4 * hh) * AS + li] = yacc[e];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
             commit(kt);
             // next step's loads go out now, unconditionally (a branch here would make the s_waitcnt placement conservative)
             const bool last = kt + 1 >= KT;
@@ -245,6 +277,13 @@ __global__ void __launch_bounds__(256, 2) gemm_wres_kernel(RowAArgs p) {   // tw
 }
 
 // LDS bytes of the resident kernel for a reduction length r and column-tile width wn (0 when it does not fit the budget)
+// the recomputing fused form: one more [32][AS] slab per wave (the activated input tile); two blocks per CU fit up to 80 KB each
+inline size_t wres_rc_lds_bytes(int r) {
+    const int rp = cdiv(r, BK) * BK;
+    const size_t bytes = ((size_t)rp * 33 + 4 * (size_t)rp + (size_t)8 * 32 * AS) * sizeof(float);
+    return bytes <= 80 * 1024 ? bytes : 0;
+}
+
 inline size_t wres_lds_bytes(int r, int wn) {
     const int rp = cdiv(r, BK) * BK;
     const size_t stage = (size_t)4 * 32 * AS;                        // also >= the 12 KiB / 8*BN floats the tails need

@@ -211,12 +211,21 @@ def test_pwconv_fwd_bwd(ctx, rng, kernel_family, m, k, n):
     ctx.call("ssdseg_pwconv_bwd_weight", H.view(dx_, dsc, dsh, act), k, gv, n, dwg, m, k, n)
     dw_ref = a.astype(np.float64).T @ dy.astype(np.float64)
     assert rel_err(dwg.download(), dw_ref) < 5e-5
-    # dx + dW in one call (one fused kernel for k <= 32, n <= 192), incl. residual + accumulate and the identity views
+    # dx + dW in one call (one fused kernel for k <= 32, n <= 192), incl. residual + accumulate and the identity views.  Its
+    # gradient view carries the conv's OWN forward output (the contract of ssdseg_pwconv_bwd: the fused kernel recomputes y from
+    # in and w instead of reading it): y of the forward call above.  The incoming gradient is zeroed where the pre-activation
+    # sits within 1e-4 of a ReLU6 threshold, so that a last-bit difference between a stored and a recomputed y cannot flip a
+    # mask that matters.
+    z_own = y.astype(np.float64) * gs + gt
+    g_own = np.where((np.abs(z_own) < 1e-4) | (np.abs(z_own - 6) < 1e-4), np.float32(0), g).astype(np.float32)
+    dy_own = gs * O.act_mask(z_own, act) * g_own.astype(np.float64) + k1 * y.astype(np.float64) + k0
+    gv_own = H.gview(ctx.array(g_own), ctx.array(y), *bufs[2:], act=O.ACT_RELU6)
+    dx_own, dw_own = dy_own @ wgt.astype(np.float64).T, a.astype(np.float64).T @ dy_own
     dwg.upload(np.zeros((k, n), np.float32))
     dxg.upload(base)
-    ctx.call("ssdseg_pwconv_bwd", H.view(dx_, dsc, dsh, act), k, gv, n, dw_, dxg, k, dwg, m, k, n, dres, k, 1)
-    assert rel_err(dxg.download(), dx_ref + res + base) < 2e-5
-    assert rel_err(dwg.download(), dw_ref) < 5e-5
+    ctx.call("ssdseg_pwconv_bwd", H.view(dx_, dsc, dsh, act), k, gv_own, n, dw_, dxg, k, dwg, m, k, n, dres, k, 1)
+    assert rel_err(dxg.download(), dx_own + res + base) < 2e-5
+    assert rel_err(dwg.download(), dw_own) < 5e-5
     ctx.call("ssdseg_pwconv_bwd", H.view(dx_), k, H.gview(bufs[0]), n, dw_, dxg, k, dwg, m, k, n, None, 0, 0)
     assert rel_err(dxg.download(), g.astype(np.float64) @ wgt.astype(np.float64).T) < 2e-5
     assert rel_err(dwg.download(), x.astype(np.float64).T @ g.astype(np.float64)) < 5e-5
