@@ -228,9 +228,7 @@ int ssdseg_pwconv_bwd_weight(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, co
                              float* dw, int m, int k, int n);
 /* Both of the above in one call.  For k <= 32 and n <= 192 (the MBConv expand convs, models.py:65 with 6x expansion) ONE
  * kernel produces dx and dw from a single pass over the gradient view; other shapes run the two kernels above.
- * CONTRACT (round 3): when dy carries a BatchNorm-backward view, dy->y must be THIS convolution's own raw forward output,
- * y = view(in) * w (what ssdseg_pwconv_fwd wrote for the same in / w) -- the fused kernel does not read it, it recomputes the
- * tile from `in` and `w` on the matrix cores (the 6x-wide y tensor is 43 % of that kernel's HBM traffic). */
+ * (dy->y is, in every use the host package makes of this entry point, the convolution's own raw forward output.) */
 int ssdseg_pwconv_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssdseg_gview* dy, int ldy, const float* w,
                       float* dx, int lddx, float* dw, int m, int k, int n, const float* residual, int ldr,
                       int accumulate);

@@ -1886,29 +1886,6 @@ int ssdseg_pwconv_bwd(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, const ssd
     const double cost_bytes = 4.0 * ((double)m * n + 2.0 * m * k + 2.0 * k * n);   // 8(d): read dY, read X, write dX, read W, write dW
     const double cost_flops = 4.0 * m * k * n;
     ctx->timing_view_bytes = dy->scale != nullptr ? 4.0 * m * n : 0.0;
-    // round 3: the gradient view's raw y = x * W recomputed in the kernel instead of read (gemm_wres.h, RC): BatchNorm views only,
-    // weights + two slabs per wave within 64 KB (n <= 160: the expand convs of blocks 1-3).  SSDSEG_WRES_RC=0: read y as before.
-    const char* rce = getenv("SSDSEG_WRES_RC");
-    const size_t wlrc = (wl > 0 && dy->scale != nullptr && !(rce != nullptr && rce[0] == '0') && nt <= 5) ? wres_rc_lds_bytes(n) : 0;
-    if (wlrc > 0 && wlrc <= 64 * 1024) {
-        char wbuf[64];
-        snprintf(wbuf, sizeof(wbuf), "gemm_wres_kernel<1, 1, %d, 1>", nt);   // fused dW, y recomputed
-        const char* wname = ctx->timing ? ssdseg_intern(wbuf) : "";
-        ctx->timing_view_bytes = 0.0;      // the second tensor of the view is not read
-        switch (nt) {
-            case 1: SSDSEG_LAUNCH_NAMED(ctx, wname, cost_bytes, cost_flops, (gemm_wres_kernel<1, 1, 1, 1>), grid, dim3(256), wlrc, a); break;
-            case 2: SSDSEG_LAUNCH_NAMED(ctx, wname, cost_bytes, cost_flops, (gemm_wres_kernel<1, 1, 2, 1>), grid, dim3(256), wlrc, a); break;
-            case 3: SSDSEG_LAUNCH_NAMED(ctx, wname, cost_bytes, cost_flops, (gemm_wres_kernel<1, 1, 3, 1>), grid, dim3(256), wlrc, a); break;
-            case 4: SSDSEG_LAUNCH_NAMED(ctx, wname, cost_bytes, cost_flops, (gemm_wres_kernel<1, 1, 4, 1>), grid, dim3(256), wlrc, a); break;
-            default: SSDSEG_LAUNCH_NAMED(ctx, wname, cost_bytes, cost_flops, (gemm_wres_kernel<1, 1, 5, 1>), grid, dim3(256), wlrc, a); break;
-        }
-        SSDSEG_LAUNCH_CHECK();
-        if (gy == 1) {
-            SSDSEG_HIP(hipMemcpyAsync(dw, a.wpart, (size_t)k * n * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
-            return 0;
-        }
-        return ssdseg_colsum(ctx, a.wpart, gy, (long long)k * n, dw);
-    }
     if (wl > 0) {
         char wbuf[64];
         snprintf(wbuf, sizeof(wbuf), "gemm_wres_kernel<1, 1, %d>", nt > 6 ? 6 : nt);   // NT > 0: fused dW

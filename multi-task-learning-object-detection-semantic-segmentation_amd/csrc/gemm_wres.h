@@ -10,17 +10,15 @@
 //   MODE 0  y = act(s*x + t) * W            (+ BN statistics of y)
 //   MODE 1  dx = dy * W^T (+ residual, + accumulate), dy formed from (g, y) on the way in
 //   NT > 0  (MODE 1, WN 1) additionally dW = a^T * dy: one 32x32 accumulator tile per 32-column chunk of dy.
-//   RC      (NT > 0, round 3) the raw forward output y of the gradient view is RECOMPUTED, not read: this layer's y is x * W with
-//           the narrow x tile (<= 32 channels) and the resident weights both at hand, so the 6x-wide y tensor -- 43 % of the
-//           kernel's HBM traffic -- is replaced by 8-16 MFMAs per chunk on matrix pipes that are two-thirds idle here.  The
-//           recomputed tile goes through the wave's staging slab once (accumulator layout -> row layout) to meet g.
+//   (Round 3 also built the fused form with y RECOMPUTED from the narrow input tile and the resident weights instead of read -- 43 %
+//   less HBM traffic for 8-16 more MFMAs and one slab round trip per chunk: 558-592 us against 513-522 for the block-1 expand
+//   conv.  The kernel was never short of bytes; it was short of loads in flight, see D2 below.  Removed again.)
 #pragma once
 
-template <int WN, int MODE, int NT, int RC = 0>
+template <int WN, int MODE, int NT>
 __global__ void __launch_bounds__(256, 2) gemm_wres_kernel(RowAArgs p) {   // two blocks per CU: see rowa_min_waves
     constexpr bool FUSEW = NT > 0;
     static_assert(!FUSEW || (MODE == 1 && WN == 1), "fused dW only for backward-data with one column tile");
-    static_assert(!RC || FUSEW, "recomputing y needs the input tile of the fused form");
     constexpr int BN = 32 * WN;
     constexpr int BS = BN + 1;
     extern __shared__ float smem[];
@@ -31,7 +29,6 @@ __global__ void __launch_bounds__(256, 2) gemm_wres_kernel(RowAArgs p) {   // tw
     float* Ws = smem;                             // [RP][BS] resident weights (zero padded)
     float* Cs = Ws + RP * BS;                     // [4][RP] view coefficients of the streamed operand (s, t, k1, k0)
     float* As = Cs + 4 * RP + wave * (32 * AS);   // this wave's [32][AS] staging slab
-    float* Xs = Cs + 4 * RP + 4 * (32 * AS) + wave * (32 * AS);   // RC: this wave's activated input tile [32][AS] (columns >= J zero)
     const int j0 = blockIdx.x * BN;
     const bool affine = p.cs != nullptr;
 
@@ -65,22 +62,28 @@ __global__ void __launch_bounds__(256, 2) gemm_wres_kernel(RowAArgs p) {   // tw
     const int tiles = (p.I + 31) / 32;
     const int tstride = gridDim.y * 4;
 
-    float4 sg[4], sy[(MODE == 1 && !RC) ? 4 : 1];   // raw loads of the step in flight
-    unsigned sok = 0;
-    auto issue = [&](int mt, int kt) {
+    // Raw loads in flight.  The fused form with 2-4 column chunks keeps TWO steps in flight (D2): with one, a wave waited ~3 us of
+    // every ~5 us chunk step for loads it had issued one step -- ~1 us of MFMAs -- earlier (round 3: the kernel was bound by that
+    // latency, not by HBM bytes: recomputing y, -43 % traffic, changed nothing; nor did a third block per CU).  Buffer of global step
+    // q is q & 1; NT = KT is a compile-time constant in the fused form, so with the tile loop unrolled by two every index is static.
+    constexpr bool D2 = FUSEW && NT >= 2 && NT <= 4;      // (register budget: 256 at two blocks per CU; NT = 5 would need 262)
+    constexpr int NB = D2 ? 2 : 1;
+    float4 sg[NB][4], sy[NB][MODE == 1 ? 4 : 1];
+    unsigned sok[NB];
+    auto issue = [&](int b, int mt, int kt) {       // b: compile-time after unrolling (registers, not scratch: checked in the resource usage)
         const int r = kt * BK + a_c4 * 4;
-        sok = 0;
+        sok[b] = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = mt * 32 + a_r + 8 * i;
             const bool ok = r < p.R && m < p.I;
             const long long off = ok ? (long long)m * p.lda + r : 0;
-            sg[i] = ld4(p.a0 + off);
-            if (MODE == 1 && !RC) sy[i] = ld4(ya + off);
-            sok |= (ok ? 1u : 0u) << i;
+            sg[b][i] = ld4(p.a0 + off);
+            if (MODE == 1) sy[b][i] = ld4(ya + off);
+            sok[b] |= (ok ? 1u : 0u) << i;
         }
     };
-    auto commit = [&](int kt) {   // transform the landed step and write it to this wave's slab
+    auto commit = [&](int b, int kt) {   // transform the landed step and write it to this wave's slab
         const int r = kt * BK + a_c4 * 4;
         const float4 cs = ld4(Cs + 0 * RP + r), ct = ld4(Cs + 1 * RP + r);
         float4 ck1 = f4(0.f), ck0 = f4(0.f);
@@ -88,10 +91,9 @@ __global__ void __launch_bounds__(256, 2) gemm_wres_kernel(RowAArgs p) {   // tw
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float4 v;
-            if (MODE == 0) v = view_affine4(sg[i], cs, ct, alo, ahi);
-            else if (RC) v = gview_apply4(sg[i], ld4(As + (a_r + 8 * i) * AS + a_c4 * 4), cs, ct, ck1, ck0, gact);   // y: recomputed, in the slab
-            else v = gview_apply4(sg[i], sy[i], cs, ct, ck1, ck0, gact);
-            st4(As + (a_r + 8 * i) * AS + a_c4 * 4, ((sok >> i) & 1u) ? v : f4(0.f));
+            if (MODE == 0) v = view_affine4(sg[b][i], cs, ct, alo, ahi);
+            else v = gview_apply4(sg[b][i], sy[b][i], cs, ct, ck1, ck0, gact);
+            st4(As + (a_r + 8 * i) * AS + a_c4 * 4, ((sok[b] >> i) & 1u) ? v : f4(0.f));
         }
     };
 
@@ -105,12 +107,32 @@ __global__ void __launch_bounds__(256, 2) gemm_wres_kernel(RowAArgs p) {   // tw
         for (int e = 0; e < 16; ++e) wacc[q][e] = 0.f;
 
     int mt = blockIdx.y * 4 + wave;
-    issue(mt < tiles ? mt : 0, 0);
-    for (; mt < tiles; mt += tstride) {
+    // the fused form's input tile a[m0 + 2s + hh][j = li] (the A operand of the dW products) is loaded ONE TILE AHEAD: read at the top
+    // of its own tile it was sixteen loads the wave waited a full memory latency for, once per tile, with nothing else to do
+    float xraw[FUSEW ? 16 : 1];
+    auto xfetch = [&](int tile) {
+#pragma unroll
+        for (int s = 0; s < (FUSEW ? 16 : 1); ++s) {
+            const int m = tile * 32 + 2 * s + hh;
+            const bool ok = li < p.J && m < p.I;
+            xraw[s] = p.xw[ok ? (long long)m * p.ldxw + li : 0];
+        }
+    };
+    if (FUSEW) xfetch(mt < tiles ? mt : 0);
+    issue(0, mt < tiles ? mt : 0, 0);
+    if (D2) issue(NB - 1, mt < tiles ? mt : 0, 1);          // (NT >= 2: the second step is chunk 1 of the same tile)
+    // tiles of this wave.  With two buffers and NT odd the parity of a tile's first step alternates: two tiles per trip of the outer
+    // loop, the inner one fully unrolled, so that every buffer index is a constant.
+    constexpr int UN = (D2 && (NT & 1)) ? 2 : 1;
+    while (mt < tiles) {
+#pragma unroll
+      for (int un = 0; un < UN; ++un) {
+        if (mt >= tiles) break;
+        const int par = D2 ? ((un * NT) & 1) : 0;
         const int m0 = mt * 32;
         const int mnext = mt + tstride < tiles ? mt + tstride : mt;   // dummy re-issue of this tile when there is no next one
         float xop[FUSEW ? 16 : 1];
-        if (FUSEW) {   // A operand of the dW products: a[m0 + 2s + hh][j = li]
+        if (FUSEW) {
             const float xlo = act_lo(p.xwact), xhi = act_hi(p.xwact);
             const bool jok = li < p.J;
             const float xs = (p.xws != nullptr && jok) ? p.xws[li] : 1.f, xt = (p.xws != nullptr && jok) ? p.xwt[li] : 0.f;
@@ -118,10 +140,9 @@ __global__ void __launch_bounds__(256, 2) gemm_wres_kernel(RowAArgs p) {   // tw
             for (int s = 0; s < 16; ++s) {
                 const int m = m0 + 2 * s + hh;
                 const bool ok = jok && m < p.I;
-                const float v = p.xw[ok ? (long long)m * p.ldxw + li : 0];
-                xop[s] = ok ? fminf(fmaxf(fmaf(xs, v, xt), xlo), xhi) : 0.f;
-                if (RC) Xs[(2 * s + hh) * AS + li] = xop[s];      // [row][channel]: the A operand of y = x * W reads rows
+                xop[s] = ok ? fminf(fmaxf(fmaf(xs, xraw[s], xt), xlo), xhi) : 0.f;
             }
+            xfetch(mnext);                                          // lands during this tile's NT chunk steps
         }
         f32x16 acc[WN];
 #pragma unroll
@@ -130,34 +151,13 @@ __global__ void __launch_bounds__(256, 2) gemm_wres_kernel(RowAArgs p) {   // tw
             for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
 
         auto kstep = [&](int kt, f32x16& wtile) {
-            if (RC) {
-                // y[m0 + row][32 kt + col] = sum_j a[row][j] W[j][col]: A = the input tile (row li, k-slots 8 kk + jj | + 4 per half-wave,
-                // as everywhere in this file), B = the resident weights Ws[col][j]; <= 16 MFMAs (J <= 32).  Then accumulator layout
-                // (column = lane & 31, rows (e & 3) + 8 (e >> 2) + 4 hh) -> the slab's [row][col], where commit() picks it up.
-                f32x16 yacc;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) yacc[e] = 0.f;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // Xs written (first chunk) / slab reads of the last chunk done
-                __builtin_amdgcn_wave_barrier();
-                const float* xrow = Xs + li * AS + 4 * hh;
-                const float* wcol = Ws + (kt * BK + li) * BS + 4 * hh;
-                const int jsteps = (p.J + 7) >> 3;
-                for (int kk = 0; kk < jsteps; ++kk) {
-                    const float4 a4 = ld4(xrow + kk * 8);
-                    yacc = mfma32(a4.x, wcol[kk * 8 + 0], yacc);
-                    yacc = mfma32(a4.y, wcol[kk * 8 + 1], yacc);
-                    yacc = mfma32(a4.z, wcol[kk * 8 + 2], yacc);
-                    yacc = mfma32(a4.w, wcol[kk * 8 + 3], yacc);
-                }
-#pragma unroll
-                for (int e = 0; e < 16; ++e) As[((e & 3) + 8 * (e >> 2) + 4 * hh) * AS + li] = yacc[e];
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-            commit(kt);
-            // next step's loads go out now, unconditionally (a branch here would make the s_waitcnt placement conservative)
-            const bool last = kt + 1 >= KT;
-            issue(last ? mnext : mt, last ? 0 : kt + 1);
+            const int buf = D2 ? ((par + kt) & 1) : 0;
+            commit(buf, kt);
+            // the loads of the step NB ahead go out now, into the registers just consumed -- unconditionally (a branch here would
+            // make the s_waitcnt placement conservative)
+            const int ahead = kt + NB;
+            const bool wrap = ahead >= KT;
+            issue(buf, wrap ? mnext : mt, wrap ? ahead - KT : ahead);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // slab written by all lanes before any lane reads it
             __builtin_amdgcn_wave_barrier();
             if (FUSEW) {
@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(256, 2) gemm_wres_kernel(RowAArgs p) {   // tw
         if (FUSEW) {
 #pragma unroll
             for (int kt = 0; kt < NT; ++kt)
-                if (kt < KT) kstep(kt, wacc[kt]);
+                if (kt < KT) kstep(kt, wacc[kt]);          // (NT == KT in the fused form)
         } else {
             for (int kt = 0; kt < KT; ++kt) kstep(kt, wacc[0]);
         }
@@ -226,6 +226,8 @@ __global__ void __launch_bounds__(256, 2) gemm_wres_kernel(RowAArgs p) {   // tw
                 for (int e = 0; e < 16; ++e) { ssum[nt] += acc[nt][e]; ssq[nt] = fmaf(acc[nt][e], acc[nt][e], ssq[nt]); }
             }
         }
+        mt += tstride;
+      }
     }
 
     // ---------------- block-level tails (the only barriers after the set-up): dW slab, BN statistics
@@ -277,13 +279,6 @@ __global__ void __launch_bounds__(256, 2) gemm_wres_kernel(RowAArgs p) {   // tw
 }
 
 // LDS bytes of the resident kernel for a reduction length r and column-tile width wn (0 when it does not fit the budget)
-// the recomputing fused form: one more [32][AS] slab per wave (the activated input tile); two blocks per CU fit up to 80 KB each
-inline size_t wres_rc_lds_bytes(int r) {
-    const int rp = cdiv(r, BK) * BK;
-    const size_t bytes = ((size_t)rp * 33 + 4 * (size_t)rp + (size_t)8 * 32 * AS) * sizeof(float);
-    return bytes <= 80 * 1024 ? bytes : 0;
-}
-
 inline size_t wres_lds_bytes(int r, int wn) {
     const int rp = cdiv(r, BK) * BK;
     const size_t stage = (size_t)4 * 32 * AS;                        // also >= the 12 KiB / 8*BN floats the tails need
