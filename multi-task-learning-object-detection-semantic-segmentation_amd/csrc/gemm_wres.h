@@ -66,7 +66,13 @@ __global__ void __launch_bounds__(256, 2) gemm_wres_kernel(RowAArgs p) {   // tw
     // every ~5 us chunk step for loads it had issued one step -- ~1 us of MFMAs -- earlier (round 3: the kernel was bound by that
     // latency, not by HBM bytes: recomputing y, -43 % traffic, changed nothing; nor did a third block per CU).  Buffer of global step
     // q is q & 1; NT = KT is a compile-time constant in the fused form, so with the tile loop unrolled by two every index is static.
-    constexpr bool D2 = FUSEW && NT >= 2 && NT <= 4;      // (register budget: 256 at two blocks per CU; NT = 5 would need 262)
+#ifndef WRES_NT5_D2
+#define WRES_NT5_D2 0
+#endif
+    // (register budget: 256 at two blocks per CU.  NT = 5 has room for the second step OR for the input tile one tile ahead, not
+    // for both: WRES_NT5_D2 picks the former)
+    constexpr bool D2 = FUSEW && NT >= 2 && NT <= (WRES_NT5_D2 ? 5 : 4);
+    constexpr bool XPRE = FUSEW && !(WRES_NT5_D2 && NT == 5);
     constexpr int NB = D2 ? 2 : 1;
     float4 sg[NB][4], sy[NB][MODE == 1 ? 4 : 1];
     unsigned sok[NB];
@@ -118,7 +124,7 @@ __global__ void __launch_bounds__(256, 2) gemm_wres_kernel(RowAArgs p) {   // tw
             xraw[s] = p.xw[ok ? (long long)m * p.ldxw + li : 0];
         }
     };
-    if (FUSEW) xfetch(mt < tiles ? mt : 0);
+    if (XPRE) xfetch(mt < tiles ? mt : 0);
     issue(0, mt < tiles ? mt : 0, 0);
     if (D2) issue(NB - 1, mt < tiles ? mt : 0, 1);          // (NT >= 2: the second step is chunk 1 of the same tile)
     // tiles of this wave.  With two buffers and NT odd the parity of a tile's first step alternates: two tiles per trip of the outer
@@ -136,13 +142,14 @@ __global__ void __launch_bounds__(256, 2) gemm_wres_kernel(RowAArgs p) {   // tw
             const float xlo = act_lo(p.xwact), xhi = act_hi(p.xwact);
             const bool jok = li < p.J;
             const float xs = (p.xws != nullptr && jok) ? p.xws[li] : 1.f, xt = (p.xws != nullptr && jok) ? p.xwt[li] : 0.f;
+            if (!XPRE) xfetch(mt);
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int m = m0 + 2 * s + hh;
                 const bool ok = jok && m < p.I;
                 xop[s] = ok ? fminf(fmaxf(fmaf(xs, xraw[s], xt), xlo), xhi) : 0.f;
             }
-            xfetch(mnext);                                          // lands during this tile's NT chunk steps
+            if (XPRE) xfetch(mnext);                                // lands during this tile's NT chunk steps
         }
         f32x16 acc[WN];
 #pragma unroll
