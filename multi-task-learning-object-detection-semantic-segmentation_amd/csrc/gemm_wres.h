@@ -66,13 +66,10 @@ __global__ void __launch_bounds__(256, 2) gemm_wres_kernel(RowAArgs p) {   // tw
     // every ~5 us chunk step for loads it had issued one step -- ~1 us of MFMAs -- earlier (round 3: the kernel was bound by that
     // latency, not by HBM bytes: recomputing y, -43 % traffic, changed nothing; nor did a third block per CU).  Buffer of global step
     // q is q & 1; NT = KT is a compile-time constant in the fused form, so with the tile loop unrolled by two every index is static.
-#ifndef WRES_NT5_D2
-#define WRES_NT5_D2 0
-#endif
-    // (register budget: 256 at two blocks per CU.  NT = 5 has room for the second step OR for the input tile one tile ahead, not
-    // for both: WRES_NT5_D2 picks the former)
-    constexpr bool D2 = FUSEW && NT >= 2 && NT <= (WRES_NT5_D2 ? 5 : 4);
-    constexpr bool XPRE = FUSEW && !(WRES_NT5_D2 && NT == 5);
+    // (register budget: 256 at two blocks per CU.  NT = 5 has room for the second step OR for the input tile one tile ahead, not for
+    // both -- 248 registers either way; measured equal within the box-to-box noise, the tile-ahead form is kept)
+    constexpr bool D2 = FUSEW && NT >= 2 && NT <= 4;
+    constexpr bool XPRE = FUSEW;
     constexpr int NB = D2 ? 2 : 1;
     float4 sg[NB][4], sy[NB][MODE == 1 ? 4 : 1];
     unsigned sok[NB];
