@@ -1,0 +1,422 @@
+// Dense 3x3 stride-1 SAME convolution (DeepLabV3+ decoder, reference blocks.py:117) forward and input gradient in the
+// WINOGRAD F(4x4, 3x3) form, fp32 throughout -- included by gemm.hip inside its anonymous namespace.
+//
+//     Y = A^T [ sum_c (G w_c G^T) .* (B^T d_c B) ] A        B^T 6x6, G 6x3, A^T 4x6 (Lavin & Gray's matrices, below)
+// 4x4 output pixels per tile from a 6x6 input tile: the reduction over input channels becomes THIRTY-SIX independent GEMMs
+// over a sixteenth of the rows -- 36/16 = 2.25 multiply-adds per output and reduction channel against 4 for F(2x2, 3x3)
+// (conv3_wino.h) and 9 for the direct sum.  The price is in the constants (B^T up to 5, A^T up to 8): measured against float64
+// at the decoder's 304 channels the result is 1.2e-5 of the output scale off (F(2x2): 8e-7, direct fp32: 4e-7;
+// scripts/study/winograd_f4x4_error.py) -- inside the 1e-3 the parity statement allows, tests hold it to 5e-5.
+//
+// One block = FOUR waves = TR x TC tiles (<= 32: the MFMA's rows; 3 x 10 for a 120 x 160 image = 12 x 40 output pixels)
+// x 32 output channels x all 36 positions; ONE block per CU, one wave per SIMD with the whole register file:
+// wave = (ra, rb) owns the 3 x 3 quadrant a in 3ra.., b in 3rb.. of the 6 x 6 position grid for all 32 tiles -- 9 x 16 = 144
+// accumulator registers per lane (64 channels would be 288: more than the 256 AGPRs the MFMAs can address -- tried, 1500 spills).
+// Per step of 16 input channels
+//   every thread     owns two STRIP tasks: the six vertically adjacent pixels (one column of one tile row) that a column of
+//                    B^T d combines, 16 bytes (four channels) of them.  It loads them (6 buffer_load_b128, issued a step
+//                    ahead; the four lanes of a pixel read 64 contiguous bytes), applies the input view, forms all six rows a
+//                    of B^T d (48 multiply-adds) and stores them to LDS -- the ROW half of the input transform is done once
+//                    per pixel column, not once per position;
+//   each lane        (tile, 4-channel quad) reads the five columns its quadrant combines for row a (5 ds_read_b128), forms
+//                    V[a][3rb..3rb+2] (28 multiply-adds) -- and those three float4 ARE the A fragments of three positions
+//                    (row = tile, lanes 0-31 channels 0-3, lanes 32-63 channels 4-7 of an 8-channel half, as in conv3_wino.h);
+//   the B fragments  (transformed weights U = G w G^T, laid out [8-channel step][position][channel][8] by
+//                    conv3_wino4_weights_kernel) come STRAIGHT from global memory into registers, 16 bytes per lane, a wave's
+//                    read of one position is 1 KB contiguous: a rolling ring of 18 float4, each reloaded for the next step
+//                    right after the MFMAs that consumed it (a whole step of latency cover).  U never touches LDS;
+//   each wave runs   3 rows x 2 halves x 3 positions x 4 = 72 v_mfma_f32_32x32x2_f32 against 30 + 12 LDS instructions.
+// Two LDS buffers of row-transformed strips, ONE barrier per step (before the last of its six MFMA blocks).
+// Blocks are ordered channel-tile-major and dealt to the XCDs in contiguous runs: an XCD works on one 32-channel slice of U
+// (1.4 MB at 304 reduction channels) at a time and keeps it in its L2 (the order made no measurable difference: SSDSEG_W4_GROUP).
+// Epilogue: the 36 x 32 x 32 accumulators go through LDS once; thread = (channel, 4 tiles) gathers the 36 values, applies
+// A^T . A in registers and writes 4 x 4 pixels (+ forward: BatchNorm partial sums, one row per pixel tile, fixed order, no atomics).
+//
+//   forward:   in = x (raw + view), U from w[i][j][c][n], reduction over c
+//   backward:  in = dy,             U from w[2-i][2-j][c][n] (the mirrored, transposed filter), reduction over n
+#pragma once
+
+constexpr int W4_THREADS = 256;
+constexpr int W4_NT = 32;                            // output channels per block
+constexpr int W4_RL = 12;                            // float4 slots of one (row a, column phase) line: pixel columns 4q + phase, q <= 11
+constexpr int W4_AROW_F = 4 * W4_RL * 4;             // floats between rows a of a strip (192)
+constexpr int W4_QP_MAX = 1040;                      // float4 slots of one 4-channel plane (>= TR * TRS, == 1 mod 16)
+constexpr int W4_VB_F = 4 * W4_QP_MAX * 4;           // floats of one buffer of row-transformed strips (16 channels = 4 planes)
+constexpr int W4_SPARE_F = 1024;                     // where threads without a strip store
+constexpr int W4_MS_LD = 33;
+constexpr int W4_MS_F = 36 * 32 * W4_MS_LD;          // epilogue: [position][tile][33]
+constexpr int W4_RED_F = 2 * 8 * 32;                 // [sum | sumsq][tile group][32]
+constexpr size_t wino4_lds_floats(int cred) {
+    const size_t loop = 2 * (size_t)W4_VB_F + W4_SPARE_F + 2 * (size_t)(cred + 16), epi = (size_t)W4_MS_F + W4_RED_F;
+    return loop > epi ? loop : epi;
+}
+
+struct Wino4Args {
+    const float* in;     // [n][in_hp][in_wp][ldi], entered at image pixel (0, 0)
+    const float* cs;     // view of the input: act(cs*x + ct); nullptr = identity
+    const float* ct;
+    int act, ldi;
+    const float* u;      // U[cred / 8][36][npad][8]
+    float* out;          // [n][h][w][ldo]
+    int ldo, accumulate;
+    float* stats;        // forward: [mtiles][2][nout] partial (sum, sumsq); may be nullptr
+    int n, h, w;
+    int cred, nout, npad;
+    int tr, tc;          // tiles per block (rows, columns), tr * tc <= 32, tc <= 11
+    int trs;             // float4 slots between tile rows in LDS (>= 24 * W4_RL, == tc mod 16)
+    int qps;             // float4 slots between 4-channel planes (>= tr * trs, == 1 mod 16, <= W4_QP_MAX)
+    int tiles_h, tiles_w, ntiles_n;
+    unsigned in_bytes, u_bytes;
+    int in_hp, in_wp;
+    int group;           // channel tiles that run side by side on one XCD (they share the input patch through its L2)
+};
+
+struct w4f4 {   // (helpers on float4: the compiler forms v_pk_fma_f32 / v_pk_add_f32 from them)
+    static __device__ __forceinline__ float4 fma(float s, float4 a, float4 b) { return make_float4(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z), fmaf(s, a.w, b.w)); }
+    static __device__ __forceinline__ float4 add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+    static __device__ __forceinline__ float4 sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+};
+
+template <bool VIEW>
+__global__ void __launch_bounds__(W4_THREADS, 1) conv3_wino4_kernel(Wino4Args p) {
+    extern __shared__ float smem[];
+    float* coef = smem + 2 * W4_VB_F + W4_SPARE_F;     // [2][cred + 16]: scale, shift of the input view
+    const int cld = p.cred + 16;
+
+    const int t = threadIdx.x;
+    const int wave = t >> 6, lane = t & 63, li = lane & 31, hh = lane >> 5;
+
+    // channel-tile-major work order, one contiguous run per XCD (blocks go to the XCDs round-robin)
+    const unsigned total = gridDim.x;
+    unsigned L = blockIdx.x;
+    if ((total & 7u) == 0u) L = (L & 7u) * (total >> 3) + (L >> 3);
+    // work order: groups of `group` channel tiles, pixel tiles within a group, the group's channel tiles innermost
+    const int mtiles = p.n * p.tiles_h * p.tiles_w;
+    const unsigned per_group = (unsigned)mtiles * (unsigned)p.group;
+    const int grp = (int)(L / per_group);
+    const unsigned lg = L - (unsigned)grp * per_group;
+    const int gsz = (grp + 1) * p.group <= p.ntiles_n ? p.group : p.ntiles_n - grp * p.group;      // (the last group may be short)
+    const int mtile = (int)(lg / (unsigned)gsz);
+    const int ntile = grp * p.group + (int)(lg - (unsigned)mtile * (unsigned)gsz);
+    const int tw = mtile % p.tiles_w;
+    const int th = (mtile / p.tiles_w) % p.tiles_h;
+    const int img = mtile / (p.tiles_w * p.tiles_h);
+    const int h0 = th * 4 * p.tr, w0 = tw * 4 * p.tc;
+    const int n0 = ntile * W4_NT;
+    const int ntl = p.tr * p.tc;                       // tiles in use (MFMA rows beyond them compute on tile 0's data, never written)
+    const int PC = 4 * p.tc + 2;                       // patch columns
+    const int M = p.cred / 16;                         // 16-channel steps
+
+    const bool affine = p.cs != nullptr;
+    const float alo = act_lo(p.act), ahi = act_hi(p.act);
+    if (VIEW) {
+        for (int i = t; i < cld; i += W4_THREADS) {
+            coef[i] = (affine && i < p.cred) ? p.cs[i] : 1.f;
+            coef[cld + i] = (affine && i < p.cred) ? p.ct[i] : 0.f;
+        }
+    }
+
+    // ---- strip role: two tasks per thread and 16-channel step, task = (strip, 16-byte chunk c of the pixel's 64 bytes): the four
+    // lanes of a pixel read one contiguous 64-byte piece -- a load instruction touches 16 cache lines, not 64 (measured: the
+    // line look-ups of 16-byte pieces scattered over 64 pixels were what the loop waited for)
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const int sc = t & 3;
+    unsigned pgo[2][6];
+    unsigned inimg[2] = {0u, 0u};
+    int swo[2][2];      // [task][buffer]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int strip = (t >> 2) + 64 * j;
+        const bool sv = strip < p.tr * PC;
+        const int str = sv ? strip / PC : 0, spc = sv ? strip - str * PC : 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int gh = h0 - 1 + 4 * str + r, gw = w0 - 1 + spc;
+            const bool ok = sv && gh >= 0 && gh < p.h && gw >= 0 && gw < p.w;
+            pgo[j][r] = ok ? (unsigned)(((((long long)img * p.in_hp + gh) * p.in_wp + gw) * p.ldi + 4 * sc) * 4) : OOB;
+            inimg[j] |= (ok ? 1u : 0u) << r;
+        }
+        // LDS slot of (quad, tile row, row a, pixel column x): quad * QPS + tr * TRS + (4a + (x & 3)) * RL + (x >> 2): the lanes of a
+        // fragment read (consecutive tiles: columns 4 apart) and of a strip store (four quads of consecutive columns; QPS = 1 mod 16)
+        // both spread over the banks
+        const int v = (sc * p.qps + str * p.trs + (spc & 3) * W4_RL + (spc >> 2)) * 4;
+        swo[j][0] = sv ? v : 2 * W4_VB_F + (t & 3) * 4;
+        swo[j][1] = sv ? v + W4_VB_F : 2 * W4_VB_F + (t & 3) * 4;
+    }
+    float4 sreg[2][6];
+    auto issue_strip = [&](int m, int j) {
+        const int soff = (m < M ? m : M - 1) * 64;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) sreg[j][r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rin, pgo[j][r], soff, 0));
+    };
+    // B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1] down the strip; half 0 = rows 0..2,
+    // half 1 = rows 3..5 (dealt to two MFMA blocks)
+    auto commit_strip = [&](int m, int j, int boff, int half) {
+        float4 d[6];
+        if (VIEW) {
+            const int c0 = (m < M ? m : M - 1) * 16 + 4 * sc;
+            const float4 cs = ld4(coef + c0), ct = ld4(coef + cld + c0);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const float keep = ((inimg[j] >> r) & 1u) ? 1.f : 0.f;      // zero padding AFTER the view
+                const float4 v = view_affine4(sreg[j][r], cs, ct, alo, ahi);
+                d[r] = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) d[r] = sreg[j][r];
+        }
+        float* dst = smem + boff;
+        if (half == 0) {
+            const float4 t1 = w4f4::fma(-4.f, d[2], d[4]), t2 = w4f4::fma(-4.f, d[1], d[3]);
+            st4(dst + 0 * W4_AROW_F, w4f4::fma(4.f, d[0], w4f4::fma(-5.f, d[2], d[4])));
+            st4(dst + 1 * W4_AROW_F, w4f4::add(t1, t2));
+            st4(dst + 2 * W4_AROW_F, w4f4::sub(t1, t2));
+        } else {
+            const float4 t3 = w4f4::sub(d[4], d[2]), t4 = w4f4::sub(d[3], d[1]);
+            st4(dst + 3 * W4_AROW_F, w4f4::fma(2.f, t4, t3));
+            st4(dst + 4 * W4_AROW_F, w4f4::fma(-2.f, t4, t3));
+            st4(dst + 5 * W4_AROW_F, w4f4::fma(4.f, d[1], w4f4::fma(-5.f, d[3], d[5])));
+        }
+    };
+
+    // ---- MFMA role: wave = quadrant (ra, rb) of the 6 x 6 position grid; lane = (tile, 4-channel quad of an 8-channel half step)
+    const int ra = __builtin_amdgcn_readfirstlane(wave >> 1), rb = __builtin_amdgcn_readfirstlane(wave & 1);
+    const int T = li < ntl ? li : 0;
+    const int ttr = T / p.tc, ttc = T - ttr * p.tc;
+    int rbase[2];       // [8-channel half kh]: quad 2 kh + hh
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) rbase[kh] = ((2 * kh + hh) * p.qps + ttr * p.trs + ttc) * 4 + 3 * ra * W4_AROW_F;
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.u_bytes, 0x00020000);
+    const unsigned ubo = n0 + li < p.nout ? (unsigned)(((n0 + li) * 8 + hh * 4) * 4) : OOB;
+    const int upos = p.npad * 32;                      // bytes of one position of one 8-channel step
+    const int ustep = 36 * upos;
+    const int ubase = (ra * 18 + rb * 3) * upos;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
+    float4 bq[6][3];                                    // [region r = 2 ai + kh][bi]
+    auto load_b = [&](int m, int r, int bi) {
+        const int soff = (2 * (m < M ? m : M - 1) + (r & 1)) * ustep + ubase + ((r >> 1) * 6 + bi) * upos;
+        bq[r][bi] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ru, ubo, soff, 0));
+    };
+    auto mfmas = [&](const float4 a, int r, int bi) {
+        const int k = (r >> 1) * 3 + bi;
+        acc[k] = mfma32(a.x, bq[r][bi].x, acc[k]);
+        acc[k] = mfma32(a.y, bq[r][bi].y, acc[k]);
+        acc[k] = mfma32(a.z, bq[r][bi].z, acc[k]);
+        acc[k] = mfma32(a.w, bq[r][bi].w, acc[k]);
+    };
+
+    // the loop, instantiated per column half RB of the quadrant (compile-time LDS offsets and transform constants)
+    auto run = [&](auto RBc) {
+        constexpr int RB = decltype(RBc)::value;
+        // the five pixel columns j = RB .. RB + 4 of the tile's six: float offsets of (phase j & 3, quad column j >> 2)
+        auto read_row = [&](int boff, int r, float4* e) {
+            const float* src = smem + boff + rbase[r & 1] + (r >> 1) * W4_AROW_F;
+#pragma unroll
+            for (int jj = 0; jj < 5; ++jj) {
+                const int j = RB + jj;
+                e[jj] = ld4(src + ((j & 3) * W4_RL + (j >> 2)) * 4);
+            }
+        };
+        // rows b of B^T applied along the columns: V[a][3RB + 0..2]
+        auto finish_row = [&](const float4* e, float4* v) {
+            if constexpr (RB == 0) {      // e = d0..d4:  b = 0: 4 d0 - 5 d2 + d4;  b = 1, 2: (d4 - 4 d2) +- (d3 - 4 d1)
+                const float4 t1 = w4f4::fma(-4.f, e[2], e[4]), t2 = w4f4::fma(-4.f, e[1], e[3]);
+                v[0] = w4f4::fma(4.f, e[0], w4f4::fma(-5.f, e[2], e[4]));
+                v[1] = w4f4::add(t1, t2);
+                v[2] = w4f4::sub(t1, t2);
+            } else {            // e = d1..d5:  b = 3, 4: (d4 - d2) +- 2 (d3 - d1);  b = 5: 4 d1 - 5 d3 + d5
+                const float4 t3 = w4f4::sub(e[3], e[1]), t4 = w4f4::sub(e[2], e[0]);
+                v[0] = w4f4::fma(2.f, t4, t3);
+                v[1] = w4f4::fma(-2.f, t4, t3);
+                v[2] = w4f4::fma(4.f, e[0], w4f4::fma(-5.f, e[2], e[4]));
+            }
+        };
+
+        float4 ev[5], av[2][3];
+        // (the order of the loads in flight at loop entry is the steady state's -- strips of the next step, then the weight
+        // fragments: the compiler's s_waitcnt counts are the minimum over both ways into the loop)
+        issue_strip(0, 0);
+        issue_strip(0, 1);
+        __syncthreads();                // coef[] visible
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { commit_strip(0, j, swo[j][0], 0); commit_strip(0, j, swo[j][0], 1); }
+        issue_strip(1, 0);
+        issue_strip(1, 1);
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int bi = 0; bi < 3; ++bi) load_b(0, r, bi);
+        __syncthreads();
+        read_row(0, 0, ev);
+        finish_row(ev, av[0]);
+
+        // One step = 16 input channels = six MFMA blocks (the quadrant's three rows x two 8-channel halves), everything else dealt
+        // into their shadow: with one wave per SIMD the matrix pipe only stays busy if the other instructions sit BETWEEN the MFMAs,
+        // so every block is one scheduling region with an explicit pattern.  Block r: the columns of block r + 1 are read and turned
+        // into its fragments; blocks 0..3 also transform half a strip each of step m + 1 into buffer `nxt` (last read before the barrier of step
+        // m - 1) and re-issue its loads for step m + 2; the ONE barrier sits before block 5, whose reads are the first of `nxt`.
+        // PH = m & 1 selects the buffers at compile time (the loop is unrolled by two).
+        auto step = [&](auto PH, int m) {
+            constexpr int ph = decltype(PH)::value;
+            constexpr int cur = ph ? W4_VB_F : 0, nxt = ph ? 0 : W4_VB_F;
+            auto block = [&](auto RC) {
+                constexpr int r = decltype(RC)::value;
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (r == 5) __syncthreads();       // strips of step m + 1 visible, buffer `cur` free
+                if constexpr (r < 5) read_row(cur, r + 1, ev);
+                else read_row(nxt, 0, ev);
+                if constexpr (r < 4) commit_strip(m + 1, r >> 1, swo[r >> 1][ph ^ 1], r & 1);
+                if constexpr (r == 1 || r == 3) issue_strip(m + 2, r >> 1);
+                finish_row(ev, av[(r + 1) & 1]);
+#pragma unroll
+                for (int bi = 0; bi < 3; ++bi) { mfmas(av[r & 1][bi], r, bi); load_b(m + 1, r, bi); }
+                __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);          // DS reads first
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, r < 4 ? 5 : 3, 0);      // VALU
+                    if constexpr (r < 4) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);       // DS write
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // VMEM read
+                }
+            };
+            block(wino_const<0>{}); block(wino_const<1>{}); block(wino_const<2>{});
+            block(wino_const<3>{}); block(wino_const<4>{}); block(wino_const<5>{});
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        int m = 0;
+        for (; m + 2 <= M; m += 2) {
+            step(wino_const<0>{}, m);
+            step(wino_const<1>{}, m + 1);
+        }
+        if (m < M) step(wino_const<0>{}, m);
+    };
+    if (rb == 0) run(wino_const<0>{});
+    else run(wino_const<1>{});
+    __syncthreads();            // every wave is done with the strip buffers: the epilogue reuses them
+
+    // ---- epilogue.  C/D layout of a 32x32 accumulator: column = lane & 31 (output channel), row = (e & 3) + 8 * (e >> 2) + 4 * hh (tile).
+    //   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]:  y = A^T m A per (tile, channel)
+    float* ms = smem;                                             // [position][tile][33]
+    float* red = smem + W4_MS_F;
+    const int ecol = t & 31, eg = t >> 5;                         // thread = (channel ecol of the half, tiles eg, eg + 8, eg + 16, eg + 24)
+    float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int pos = (3 * ra + k / 3) * 6 + 3 * rb + k % 3;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int tl = (e & 3) + 8 * (e >> 2) + 4 * hh;
+            ms[(pos * 32 + tl) * W4_MS_LD + li] = acc[k][e];
+        }
+    }
+    __syncthreads();
+    const int j = n0 + ecol;
+    const bool jok = j < p.nout;
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) {
+        const int tl = eg + 8 * r;
+        const int tr2 = tl / p.tc, tc2 = tl - tr2 * p.tc;
+        float c[4][6];      // A^T m: rows i, columns b
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            float m[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) m[a] = ms[((a * 6 + b) * 32 + tl) * W4_MS_LD + ecol];
+            const float pp = m[1] + m[2], qq = m[1] - m[2], rr = m[3] + m[4], uu = m[3] - m[4];
+            c[0][b] = m[0] + pp + rr;
+            c[1][b] = fmaf(2.f, uu, qq);
+            c[2][b] = fmaf(4.f, rr, pp);
+            c[3][b] = fmaf(8.f, uu, qq) + m[5];
+        }
+        const int oh = h0 + 4 * tr2, ow = w0 + 4 * tc2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float pp = c[i][1] + c[i][2], qq = c[i][1] - c[i][2], rr = c[i][3] + c[i][4], uu = c[i][3] - c[i][4];
+            const float yv[4] = {c[i][0] + pp + rr, fmaf(2.f, uu, qq), fmaf(4.f, rr, pp), fmaf(8.f, uu, qq) + c[i][5]};
+#pragma unroll
+            for (int jx = 0; jx < 4; ++jx) {
+                if (jok && tl < ntl && oh + i < p.h && ow + jx < p.w) {
+                    float* dst = p.out + (((long long)img * p.h + oh + i) * p.w + ow + jx) * p.ldo + j;
+                    float val = yv[jx];
+                    if (p.accumulate) val += *dst;
+                    *dst = val;
+                    ssum += yv[jx];
+                    ssq = fmaf(yv[jx], yv[jx], ssq);
+                }
+            }
+        }
+    }
+    if (p.stats != nullptr) {
+        red[(0 * 8 + eg) * 32 + ecol] = ssum;
+        red[(1 * 8 + eg) * 32 + ecol] = ssq;
+        __syncthreads();
+        if (t < 2 * W4_NT) {
+            const int which = t / W4_NT, col = t - which * W4_NT, j2 = n0 + col;
+            if (j2 < p.nout) {
+                float v = 0.f;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) v += red[(which * 8 + g) * 32 + col];
+                p.stats[((long long)mtile * 2 + which) * p.nout + j2] = v;
+            }
+        }
+    }
+}
+
+// U = G w G^T per (input channel, output channel) pair, G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1],
+// stored in the order the conv kernel streams it: U[step = r / 8][position 6a + b][o (padded to whole 64-channel blocks)][r % 8], r the
+// reduction channel, o the output channel.  mode 0 (forward): r = c, o = n, from w[i][j][c][n];  mode 1 (input gradient): r = n, o = c,
+// from w[2-i][2-j][c][n].  One 32 x 32 (c, n) tile per block through LDS.
+__global__ void __launch_bounds__(256) conv3_wino4_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int cin, int cout, int mode) {
+    const int opad = (mode == 0 ? (cout + W4_NT - 1) / W4_NT : (cin + W4_NT - 1) / W4_NT) * W4_NT;
+    __shared__ float tile[9][32][33];
+    const int c0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int tap = 0; tap < 9; ++tap)
+        for (int r = ty; r < 32; r += 8) {
+            const int c = c0 + r, n = n0 + tx;
+            tile[tap][r][tx] = (c < cin && n < cout) ? w[((long long)tap * cin + c) * cout + n] : 0.f;
+        }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        // forward: this thread writes (n = n0 + r, c = c0 + tx); gradient: (c = c0 + r, n = n0 + tx)
+        const int cl = mode == 0 ? tx : r, nl = mode == 0 ? r : tx;
+        const int c = c0 + cl, n = n0 + nl;
+        if (c >= cin || n >= cout) continue;
+        float g[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) g[i][j] = mode == 0 ? tile[i * 3 + j][cl][nl] : tile[(2 - i) * 3 + (2 - j)][cl][nl];
+        float gw[6][3];       // G w
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float s02 = g[0][j] + g[2][j];
+            gw[0][j] = 0.25f * g[0][j];
+            gw[1][j] = (-1.f / 6.f) * (s02 + g[1][j]);
+            gw[2][j] = (-1.f / 6.f) * (s02 - g[1][j]);
+            gw[3][j] = (1.f / 24.f) * g[0][j] + (1.f / 12.f) * g[1][j] + (1.f / 6.f) * g[2][j];
+            gw[4][j] = (1.f / 24.f) * g[0][j] - (1.f / 12.f) * g[1][j] + (1.f / 6.f) * g[2][j];
+            gw[5][j] = g[2][j];
+        }
+        const int rr = mode == 0 ? c : n, oo = mode == 0 ? n : c;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const float s02 = gw[a][0] + gw[a][2];
+            const float o[6] = {0.25f * gw[a][0],
+                                (-1.f / 6.f) * (s02 + gw[a][1]),
+                                (-1.f / 6.f) * (s02 - gw[a][1]),
+                                (1.f / 24.f) * gw[a][0] + (1.f / 12.f) * gw[a][1] + (1.f / 6.f) * gw[a][2],
+                                (1.f / 24.f) * gw[a][0] - (1.f / 12.f) * gw[a][1] + (1.f / 6.f) * gw[a][2],
+                                gw[a][2]};
+#pragma unroll
+            for (int b = 0; b < 6; ++b) u[((((long long)(rr >> 3) * 36 + a * 6 + b) * opad + oo) << 3) + (rr & 7)] = o[b];
+        }
+    }
+}

@@ -62,10 +62,6 @@ struct RowAArgs {
     const float* xwt;
     int xwact, ldxw;
     float* wpart;
-    // split-K (gridDim.z > 1): block z reduces the steps [z*ksteps, (z+1)*ksteps) and writes its raw partial tile to
-    // kpart[z][I][J]; bias / residual / accumulate / statistics then belong to splitk_reduce_kernel
-    int ksteps;
-    float* kpart;
     // BNE (MODE 1): BatchNorm backward of the producer of this conv's INPUT, fused into the (LDS-transposed, float4) epilogue:
     // raw input bn_y[I][J] (ld ldby), that BN's scale/shift/mean/invstd/activation; bnpart: [gridDim.y][2][J] partial rows of
     // (sum mask*dx, sum mask*dx*xhat)
@@ -270,8 +266,7 @@ __global__ void __launch_bounds__(256, OCC ? rowa_min_waves(WN, MODE, NT) : 1) g
             xop[s] = ok ? fminf(fmaxf(fmaf(xs, v, xt), xlo), xhi) : 0.f;
         }
     }
-    const int kt0 = gridDim.z > 1 ? (int)blockIdx.z * p.ksteps : 0;
-    const int kt1 = gridDim.z > 1 ? (kt0 + p.ksteps < KT ? kt0 + p.ksteps : KT) : KT;
+    const int kt0 = 0, kt1 = KT;
     load_tiles(kt0);
     // one 32-deep reduction step; `wtile` = which dW accumulator this step feeds (a compile-time constant in the fused loop)
     auto kstep = [&](int kt, f32x16& wtile) {
@@ -438,10 +433,6 @@ __global__ void __launch_bounds__(256, OCC ? rowa_min_waves(WN, MODE, NT) : 1) g
                 const int m = m0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
                 if (m < p.I) {
                     float v = acc[nt][e];
-                    if (gridDim.z > 1) {   // split-K partial: raw sums only
-                        p.kpart[((long long)blockIdx.z * p.I + m) * p.J + j] = v;
-                        continue;
-                    }
                     if (STEM && p.bias) v += p.bias[j];
                     if (MODE == 1) {
                         if (p.residual) v += p.residual[(long long)m * p.ldr + j];
@@ -906,6 +897,7 @@ int rowA_wn(int rows, int cols) {
 #include "conv3_wgrad_tile.h"
 #include "pw_tile.h"
 #include "conv3_wino.h"
+#include "conv3_wino4.h"
 #include "conv3_wino_wgrad.h"
 #include "pw_wgrad.h"
 
@@ -1068,62 +1060,6 @@ int rowA_grid_y_wn(int rows, int cols, int wn) {
     return cdiv(mtiles, per);
 }
 
-// out[m][j] = sum_z part[z][m][j] (+ residual) (+ previous out), float4 per thread, plus (optionally) the BatchNorm statistics
-// of the result as one partial row per block -- the tail of a split-K launch.  J % 4 == 0, J <= 1024, 16-byte aligned rows.
-__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ part, int S, int I, int J, float* __restrict__ out,
-                                                             int ldo, const float* __restrict__ residual, int ldr, int accumulate,
-                                                             float* __restrict__ stats) {
-    __shared__ float4 sred[2 * 256];
-    const int cv = J / 4;
-    const int rpp = 256 / cv;   // rows per pass
-    const int t = threadIdx.x;
-    const int r = t / cv, c4 = t - r * cv;
-    const bool act = r < rpp;
-    float4 s = f4(0.f), q = f4(0.f);
-    const int mtiles = (I + BM - 1) / BM;
-    for (int tile = blockIdx.x; tile < mtiles; tile += gridDim.x) {
-        const int rend = (tile + 1) * BM < I ? (tile + 1) * BM : I;
-        for (int row = tile * BM + r; act && row < rend; row += rpp) {
-            float4 v = f4(0.f);
-            for (int z = 0; z < S; ++z) {
-                const float4 pz = ld4(part + ((long long)z * I + row) * J + c4 * 4);
-                v.x += pz.x; v.y += pz.y; v.z += pz.z; v.w += pz.w;
-            }
-            if (residual != nullptr) {
-                const float4 rz = ld4(residual + (long long)row * ldr + c4 * 4);
-                v.x += rz.x; v.y += rz.y; v.z += rz.z; v.w += rz.w;
-            }
-            float* o = out + (long long)row * ldo + c4 * 4;
-            if (accumulate) {
-                const float4 pv = ld4(o);
-                v.x += pv.x; v.y += pv.y; v.z += pv.z; v.w += pv.w;
-            }
-            st4(o, v);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-            q.x = fmaf(v.x, v.x, q.x); q.y = fmaf(v.y, v.y, q.y); q.z = fmaf(v.z, v.z, q.z); q.w = fmaf(v.w, v.w, q.w);
-        }
-    }
-    if (stats == nullptr) return;
-    sred[t] = s;
-    sred[256 + t] = q;
-    __syncthreads();
-    if (t < cv) {   // r == 0: fold the block's row lanes in a fixed order
-        float4 a = f4(0.f), b = f4(0.f);
-        for (int k = 0; k < rpp; ++k) {
-            const float4 x = sred[k * cv + t], y = sred[256 + k * cv + t];
-            a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
-            b.x += y.x; b.y += y.y; b.z += y.z; b.w += y.w;
-        }
-        st4(stats + ((long long)blockIdx.x * 2 + 0) * J + t * 4, a);
-        st4(stats + ((long long)blockIdx.x * 2 + 1) * J + t * 4, b);
-    }
-}
-
-// Off by default: measured on MI355X it is a wash (backbone step 14.68 ms without, 14.93 ms with) -- the operand re-reads it
-// removes were already served by the 256 MiB Infinity Cache, and the partial tiles + reduce kernel cost what was saved.
-// SSDSEG_SPLITK=1 enables it (read per call; the parity tests run that family too).
-bool splitk_enabled() { return getenv("SSDSEG_SPLITK") != nullptr && getenv("SSDSEG_SPLITK")[0] == '1'; }
-
 // wt_pre (forward only, may be nullptr): the weights already transposed to [J][R] by ssdseg_transpose_batch
 template <int MODE, int LD>
 int launch_rowA(ssdseg_ctx* ctx, const RowAArgs& a0, const float* wt_pre = nullptr) {
@@ -1150,42 +1086,17 @@ int launch_rowA(ssdseg_ctx* ctx, const RowAArgs& a0, const float* wt_pre = nullp
         }
         return pw_tile_launch<MODE>(ctx, t, a.stats != nullptr ? nparts : 0, (MODE == 1 && a.cs != nullptr) ? 4.0 * a.I * a.R : 0.0);
     }
-    int splits = 1;
-    // Few row tiles and a long reduction (the 30x40 / 15x20 stages): the default picks narrow column tiles to get enough blocks,
-    // so every column tile re-reads the (up to 960-wide, two-tensor) streamed operand -- 3-5x the algorithmic traffic, bound by
-    // L2.  Here the tile spans all columns (operand read once) and the reduction is split across blocks instead; a small second
-    // kernel sums the partial tiles and takes over bias-free epilogue duties (residual, accumulate, BN statistics).
-    if (LD == 0 && splitk_enabled() && a.R >= 256 && a.J <= 160 && a.J % 4 == 0 && a.ldo % 4 == 0 && ((uintptr_t)a.out & 15) == 0 &&
-        (a.residual == nullptr || (a.ldr % 4 == 0 && ((uintptr_t)a.residual & 15) == 0))) {
-        const int wide = cdiv(a.J, 32);
-        const int mtiles = cdiv(a.I, BM), ksteps_total = cdiv(a.R, BK);
-        if (wide > wn && mtiles < 4 * ctx->num_cus) {
-            wn = wide;
-            int s = cdiv(2 * ctx->num_cus, mtiles);
-            if (s > ksteps_total / 4) s = ksteps_total / 4;
-            if (s >= 2) splits = s;
-        }
-    }
     // Backward-data of the 30x40-stage expand convs (38400 rows = 300 row tiles, 384-576 reduction channels of a TWO-tensor
     // gradient view, 64-96 output columns): the default picks 32-column tiles to have 600-900 blocks, and every column tile
     // re-reads the whole (g, y) operand from the fabric (measured 5 TB/s of L2-level reads for 1.4 TB/s algorithmic).  One
     // column tile spanning all outputs reads it once; with >= 256 row tiles there is still a block per CU (109 -> 88 us).
     // Not for the 15x20 stage (75 row tiles: 2x slower) and no gain for the forward (single-tensor operand).
     int grid_y = (MODE == 1 && LD == 0) ? rowA_grid_y_wn(a.I, a.J, wn) : nparts;   // (no statistics table in backward-data: free choice)
-    if (MODE == 1 && LD == 0 && splits == 1 && a.cs != nullptr && a.R >= 256) {
+    if (MODE == 1 && LD == 0 && a.cs != nullptr && a.R >= 256) {
         const int wide = cdiv(a.J, 32), mtiles = cdiv(a.I, BM);
         if (wide > wn && wide <= 3 && mtiles >= 256 && a.I < ROWA_OCC_ROWS) { wn = wide; grid_y = mtiles < 2048 ? mtiles : 2048; }
     }
-    dim3 grid(cdiv(a.J, 32 * wn), splits > 1 ? cdiv(a.I, BM) : grid_y, splits);
-    float* stats_out = a.stats;
-    if (splits > 1) {
-        void* ws;
-        int rc = ssdseg_workspace(ctx, (size_t)splits * a.I * a.J * sizeof(float), &ws);
-        if (rc) return rc;
-        a.kpart = (float*)ws;
-        a.ksteps = cdiv(cdiv(a.R, BK), splits);
-        a.stats = nullptr;
-    }
+    dim3 grid(cdiv(a.J, 32 * wn), grid_y);
     size_t lds = (size_t)(BM * AS + BK * (32 * wn + 1)) * sizeof(float);
     size_t red = (size_t)(4 * 2 * 32 * wn) * sizeof(float);
     if (red > lds) lds = red;
@@ -1220,7 +1131,7 @@ int launch_rowA(ssdseg_ctx* ctx, const RowAArgs& a0, const float* wt_pre = nullp
     }
     // wide, 16-byte-aligned outputs leave through the LDS-transposed float4 epilogue (16 B per lane instead of 4)
     const char* f4env = getenv("SSDSEG_NO_F4_EPILOGUE");
-    if (LD == 0 && splits == 1 && wn >= 2 && !(f4env != nullptr && f4env[0] == '1') && a.J % 4 == 0 && a.ldo % 4 == 0 &&
+    if (LD == 0 && wn >= 2 && !(f4env != nullptr && f4env[0] == '1') && a.J % 4 == 0 && a.ldo % 4 == 0 &&
         ((uintptr_t)a.out & 15) == 0 && (a.residual == nullptr || (a.ldr % 4 == 0 && ((uintptr_t)a.residual & 15) == 0))) {
         const size_t cs = (size_t)64 * (32 * wn + 4) * sizeof(float);
         if (cs > lds) lds = cs;
@@ -1273,11 +1184,6 @@ int launch_rowA(ssdseg_ctx* ctx, const RowAArgs& a0, const float* wt_pre = nullp
             break;
     }
     SSDSEG_LAUNCH_CHECK();
-    if (splits > 1) {
-        SSDSEG_LAUNCH(ctx, 4.0 * ((double)splits + 1.0) * a.I * a.J, 0.0, splitk_reduce_kernel, dim3(nparts), dim3(256), 0, (const float*)a.kpart,
-                      splits, a.I, a.J, a.out, a.ldo, a.residual, a.ldr, a.accumulate, stats_out);
-        SSDSEG_LAUNCH_CHECK();
-    }
     return 0;
 }
 
@@ -1621,7 +1527,10 @@ bool conv3_wino_takes(int n, int h, int w, int cred, int nout) {
 }
 
 // a: in / view / out / stats / shape as for conv3t_launch; w = the layer's [3][3][cin][cout] weights; mode 0 forward, 1 input gradient
+int conv3_wino4_launch(ssdseg_ctx* ctx, const Conv3TArgs& a, const float* w, int cin, int cout, int mode);
+bool conv3_wino4_takes(int n, int h, int w, int cred, int nout);
 int conv3_wino_launch(ssdseg_ctx* ctx, Conv3TArgs a, const float* w, int cin, int cout, int mode) {
+    if (conv3_wino4_takes(a.n, a.h, a.w, a.cred, a.nout)) return conv3_wino4_launch(ctx, a, w, cin, cout, mode);
     void* ws;
     const int npad = cdiv(a.nout, WINO_NT) * WINO_NT;
     const size_t ubytes = (size_t)16 * a.cred * npad * sizeof(float);      // U[cred / 8][16][npad][8]
@@ -1656,6 +1565,81 @@ int conv3_wino_launch(ssdseg_ctx* ctx, Conv3TArgs a, const float* w, int cin, in
         SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, conv3_wino_kernel<true>, dim3((unsigned)(mtiles * a.ntiles_n)), dim3(C3T_THREADS), lds, a);
     else
         SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, conv3_wino_kernel<false>, dim3((unsigned)(mtiles * a.ntiles_n)), dim3(C3T_THREADS), lds, a);
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- Winograd F(4x4, 3x3) form (conv3_wino4.h): forward / input gradient of the layers the F(2x2) form takes, where a tile
+// geometry exists.  SSDSEG_CONV3_F4=0: never, =1: wherever it fits (parity tests); unset: the large layers.
+struct Wino4Geom { int tr, tc, trs, tiles_h, tiles_w; };
+bool wino4_geometry(int h, int w, Wino4Geom* g) {
+    long long best = -1;
+    for (int tc = 1; tc <= 11; ++tc)
+        for (int tr = 1; tr * tc <= 32; ++tr) {
+            if (4 * tr * (4 * tc + 2) > 2 * W4_THREADS) continue;      // strips x four 16-byte chunks: two tasks per thread
+            int trs = 24 * W4_RL;
+            while ((trs & 15) != (tc & 15)) ++trs;
+            if (tr * trs + 15 > W4_QP_MAX) continue;            // (+ the round-up of the plane stride to 1 mod 16)
+            const long long blocks = (long long)cdiv(h, 4 * tr) * cdiv(w, 4 * tc);
+            // fewest blocks (every block costs a full 32-row MFMA pass); then the squarer patch (less halo)
+            const long long key = blocks * 1024 + (tr > tc ? tr - tc : tc - tr);
+            if (best < 0 || key < best) { best = key; *g = Wino4Geom{tr, tc, trs, cdiv(h, 4 * tr), cdiv(w, 4 * tc)}; }
+        }
+    return best >= 0;
+}
+bool conv3_wino4_takes(int n, int h, int w, int cred, int nout) {
+    const char* e = getenv("SSDSEG_CONV3_F4");
+    if (e != nullptr && e[0] == '0') return false;
+    if (!conv3_wino_takes(n, h, w, cred, nout) || cred % 16 != 0 || wino4_lds_floats(cred) * sizeof(float) > (size_t)160 * 1024) return false;
+    Wino4Geom g;
+    if (!wino4_geometry(h, w, &g)) return false;
+    if ((long long)36 * cred * cdiv(nout, W4_NT) * W4_NT * 4 >= (1LL << 31)) return false;
+    if (e != nullptr && e[0] == '1') return true;
+    return false;
+}
+
+int conv3_wino4_launch(ssdseg_ctx* ctx, const Conv3TArgs& a, const float* w, int cin, int cout, int mode) {
+    Wino4Geom g;
+    if (!wino4_geometry(a.h, a.w, &g)) return SSDSEG_EINVAL(6);
+    void* ws;
+    const int npad = cdiv(a.nout, W4_NT) * W4_NT;
+    const size_t ubytes = (size_t)36 * a.cred * npad * sizeof(float);      // U[cred / 8][36][npad][8]
+    int rc = ssdseg_workspace(ctx, ubytes, &ws);
+    if (rc) return rc;
+    SSDSEG_LAUNCH(ctx, 4.0 * (9 + 36) * cin * cout, 0.0, conv3_wino4_weights_kernel, dim3(cdiv(cout, 32), cdiv(cin, 32)), dim3(256), 0, w, (float*)ws, cin, cout, mode);
+    SSDSEG_LAUNCH_CHECK();
+    Wino4Args p{};
+    p.in = a.in; p.cs = a.cs; p.ct = a.ct; p.act = a.act; p.ldi = a.ldi;
+    p.u = (const float*)ws;
+    p.out = a.out; p.ldo = a.ldo; p.accumulate = a.accumulate; p.stats = a.stats;
+    p.n = a.n; p.h = a.h; p.w = a.w; p.cred = a.cred; p.nout = a.nout; p.npad = npad;
+    p.tr = g.tr; p.tc = g.tc; p.trs = g.trs;
+    p.qps = g.tr * g.trs;
+    while ((p.qps & 15) != 1) ++p.qps; p.tiles_h = g.tiles_h; p.tiles_w = g.tiles_w; p.ntiles_n = npad / W4_NT;
+    p.in_hp = a.in_hp ? a.in_hp : a.h; p.in_wp = a.in_hp ? a.in_wp : a.w;
+    p.in_bytes = (unsigned)(((((long long)(a.n - 1) * p.in_hp + a.h - 1) * p.in_wp + a.w - 1) * a.ldi + a.cred) * 4);
+    p.u_bytes = (unsigned)ubytes;
+    { const char* e = getenv("SSDSEG_W4_GROUP"); p.group = e ? atoi(e) : 1; if (p.group < 1) p.group = 1; if (p.group > p.ntiles_n) p.group = p.ntiles_n; }
+    const size_t lds = wino4_lds_floats(a.cred) * sizeof(float);
+    static size_t configured = 0;
+    if (lds > configured) {
+        SSDSEG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wino4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SSDSEG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wino4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    const double m = (double)a.n * a.h * a.w;
+    const double cost_bytes = 4.0 * (m * a.cred + m * a.nout + 9.0 * a.cred * a.nout);   // X + Y + W
+    // flops EXECUTED on the MFMA pipe: 36 positions x (m / 16) tiles x 2 cred nout = 4.5 m cred nout -- a quarter of the direct sum's 18
+    const double cost_flops = 4.5 * m * a.cred * a.nout;
+    const int mtiles = a.n * g.tiles_h * g.tiles_w;
+    const bool with_view = a.cs != nullptr || a.act != SSDSEG_ACT_NONE;
+    char kbuf[64];
+    snprintf(kbuf, sizeof(kbuf), "conv3_wino4_kernel<%s> [%s]", with_view ? "true" : "false", mode ? "bwd_data" : "fwd");
+    const char* kname = ctx->timing ? ssdseg_intern(kbuf) : "";
+    if (with_view)
+        SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, conv3_wino4_kernel<true>, dim3((unsigned)(mtiles * p.ntiles_n)), dim3(W4_THREADS), lds, p);
+    else
+        SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, conv3_wino4_kernel<false>, dim3((unsigned)(mtiles * p.ntiles_n)), dim3(W4_THREADS), lds, p);
     SSDSEG_LAUNCH_CHECK();
     return 0;
 }
@@ -2165,6 +2149,12 @@ int ssdseg_conv3x3_parts(int n, int h, int w, int cin, int cout, int* nparts_hos
     SSDSEG_ARG(cout > 0 && cout % 4 == 0, 5);
     SSDSEG_ARG(nparts_host != nullptr, 6);
     // the halo-tile kernel writes one partial row per 8 x 32 pixel tile, the implicit-GEMM kernels one per row-tile slot
+    if (conv3_tile_fwd_ok(cin, cout) && conv3_wino4_takes(n, h, w, cin, cout)) {      // (one row per block of 4x4-pixel tiles)
+        Wino4Geom g;
+        wino4_geometry(h, w, &g);
+        *nparts_host = n * g.tiles_h * g.tiles_w;
+        return 0;
+    }
     *nparts_host = conv3_tile_fwd_ok(cin, cout) ? conv3t_geometry(n, h, w, cout).mtiles : rowA_grid_y(n * h * w, cout);
     return 0;
 }

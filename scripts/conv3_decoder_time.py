@@ -21,7 +21,14 @@ wgt = ctx.array((rng.normal(0, 1, (3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(
 dy = ctx.array(rng.normal(0, 1, (n, h, w, cout)).astype(np.float32))
 y, dx, dw = ctx.empty((n, h, w, cout)), ctx.empty((n, h, w, cin)), ctx.empty((3, 3, cin, cout))
 nparts = ctx.parts("ssdseg_conv3x3_parts", n, h, w, cin, cout)
-stats = ctx.empty((nparts, 2, cout))
+_keep = os.environ.get("SSDSEG_CONV3_WINOGRAD")
+os.environ["SSDSEG_CONV3_WINOGRAD"] = "0"      # (the direct kernels of the parity check write one row per 8 x 32 tile: size for both)
+nparts = max(nparts, ctx.parts("ssdseg_conv3x3_parts", n, h, w, cin, cout))
+if _keep is None:
+    del os.environ["SSDSEG_CONV3_WINOGRAD"]
+else:
+    os.environ["SSDSEG_CONV3_WINOGRAD"] = _keep
+stats = ctx.zeros((nparts, 2, cout))
 
 
 def run():
@@ -39,11 +46,12 @@ for name, r in ctx.timing_report().items():
     if r["count"]:
         ms = r["ms"] / r["count"]
         tf = r['flops'] / r['count'] / ms / 1e9 if ms else 0
-        print(f"{name[:60]:60s} x{r['count']:3d}  {ms:8.3f} ms/launch  {tf:7.1f} TF" + (f"  ({tf * 2.25:6.1f} TF direct-equivalent)" if "wino" in name and tf else ""))
+        print(f"{name[:60]:60s} x{r['count']:3d}  {ms:8.3f} ms/launch  {tf:7.1f} TF" + (f"  ({tf * (4.0 if 'wino4' in name else 2.25):6.1f} TF direct-equivalent)" if "wino" in name and tf else ""))
 ctx.timing(False)
 got = {"y": y.download(), "dx": dx.download(), "dw": dw.download(), "stats": stats.download().sum(0)}
 if os.environ.get("SSDSEG_CONV3_WINOGRAD", "") != "0":
     os.environ["SSDSEG_CONV3_WINOGRAD"] = "0"
+    stats.upload(np.zeros((nparts, 2, cout), np.float32))
     run(); ctx.sync()
     ref = {"y": y.download(), "dx": dx.download(), "dw": dw.download(), "stats": stats.download().sum(0)}
     for k in got:

@@ -21,7 +21,6 @@ KERNEL_FAMILIES = {
                 "SSDSEG_CONV3_NARROW": "0", "SSDSEG_PW_TILE": "0", "SSDSEG_CONV3_TILE": "0", "SSDSEG_PW_WGRAD": "0", "SSDSEG_DW_FWD_DEPTH": "1"},
     "general-reg": {"SSDSEG_NO_WRES": "1", "SSDSEG_DW_FWD": "lds", "SSDSEG_DW_BWD": "reg", "SSDSEG_PW_TILE": "0", "SSDSEG_PW_WGRAD": "0"},
     "resident-fused": {"SSDSEG_WRES_FORCE": "1", "SSDSEG_PW_FUSED": "1", "SSDSEG_PW_TILE": "0"},
-    "split-k": {"SSDSEG_NO_WRES": "1", "SSDSEG_SPLITK": "1", "SSDSEG_PW_TILE": "0", "SSDSEG_PW_WGRAD": "0", "SSDSEG_DW_FWD_DEPTH": "1"},
     # round 2: the double-buffered tile GEMMs (pw_tile.h) for every shape they take, OCC-limited rowA instantiations for the rest;
     # the row-naming weight-gradient kernel (pw_wgrad.h) and the two-rows-ahead depthwise forward are on in "default",
     # "resident-fused" and "tile", off in the others
@@ -31,7 +30,7 @@ KERNEL_FAMILIES = {
     "tile-32": {"SSDSEG_PW_TILE": "1", "SSDSEG_PWT_SMALL": "32"},
     "tile-wide": {"SSDSEG_PW_TILE": "1", "SSDSEG_PWT_SMALL": "0"},
 }
-_FAMILY_VARS = ("SSDSEG_NO_WRES", "SSDSEG_WRES_FORCE", "SSDSEG_PW_FUSED", "SSDSEG_DW_FWD", "SSDSEG_DW_BWD", "SSDSEG_SPLITK", "SSDSEG_CONV3_WGRAD",
+_FAMILY_VARS = ("SSDSEG_NO_WRES", "SSDSEG_WRES_FORCE", "SSDSEG_PW_FUSED", "SSDSEG_DW_FWD", "SSDSEG_DW_BWD", "SSDSEG_CONV3_WGRAD",
                 "SSDSEG_CONV3_NARROW", "SSDSEG_PW_TILE", "SSDSEG_CONV3_TILE", "SSDSEG_CONV3_WINOGRAD", "SSDSEG_OCC_ROWS", "SSDSEG_PW_WGRAD",
                 "SSDSEG_DW_FWD_DEPTH", "SSDSEG_PWT_SMALL")
 
