@@ -44,11 +44,11 @@ constexpr int W4_QP_MAX = 1040;                      // float4 slots of one 4-ch
 constexpr int W4_VB_F = 4 * W4_QP_MAX * 4;           // floats of one buffer of row-transformed strips (16 channels = 4 planes)
 constexpr int W4_SPARE_F = 1024;                     // where threads without a strip store
 constexpr int W4_MS_LD = 33;
-constexpr int W4_MS_F = 36 * 32 * W4_MS_LD;          // epilogue: [position][tile][33]
-constexpr int W4_RED_F = 2 * 8 * 32;                 // [sum | sumsq][tile group][32]
+constexpr int W4_MS_F = 36 * 8 * W4_MS_LD;           // epilogue staging, one round: [position][8 tiles][33]
+constexpr int W4_RED_F = 2 * 8 * 32;                 // [sum | sumsq][tile group][32] (in the spare area)
 constexpr size_t wino4_lds_floats(int cred) {
-    const size_t loop = 2 * (size_t)W4_VB_F + W4_SPARE_F + 2 * (size_t)(cred + 16), epi = (size_t)W4_MS_F + W4_RED_F;
-    return loop > epi ? loop : epi;
+    static_assert(W4_MS_F <= W4_VB_F && W4_RED_F <= W4_SPARE_F, "the epilogue staging lives in buffer 1 / the spare area");
+    return 2 * (size_t)W4_VB_F + W4_SPARE_F + 2 * (size_t)(cred + 16);
 }
 
 struct Wino4Args {
@@ -68,7 +68,7 @@ struct Wino4Args {
     int tiles_h, tiles_w, ntiles_n;
     unsigned in_bytes, u_bytes;
     int in_hp, in_wp;
-    int group;           // channel tiles that run side by side on one XCD (they share the input patch through its L2)
+    unsigned long long* trace;   // measurement only (SSDSEG_W4_TRACE): per block and item, the clock at loop start / loop end / item end
 };
 
 struct w4f4 {   // (helpers on float4: the compiler forms v_pk_fma_f32 / v_pk_add_f32 from them)
@@ -86,23 +86,15 @@ __global__ void __launch_bounds__(W4_THREADS, 1) conv3_wino4_kernel(Wino4Args p)
     const int t = threadIdx.x;
     const int wave = t >> 6, lane = t & 63, li = lane & 31, hh = lane >> 5;
 
-    // channel-tile-major work order, one contiguous run per XCD (blocks go to the XCDs round-robin)
-    const unsigned total = gridDim.x;
-    unsigned L = blockIdx.x;
-    if ((total & 7u) == 0u) L = (L & 7u) * (total >> 3) + (L >> 3);
-    // work order: groups of `group` channel tiles, pixel tiles within a group, the group's channel tiles innermost
+    // PERSISTENT blocks, one per CU: a block walks its share of the work items (pixel tile x 32-channel tile), and the first loads
+    // of the next item are in flight while the current one leaves through its epilogue.  Work order: channel-tile-major, one
+    // contiguous run per XCD (blocks go to the XCDs round-robin), the blocks of an XCD interleaved within its run.
     const int mtiles = p.n * p.tiles_h * p.tiles_w;
-    const unsigned per_group = (unsigned)mtiles * (unsigned)p.group;
-    const int grp = (int)(L / per_group);
-    const unsigned lg = L - (unsigned)grp * per_group;
-    const int gsz = (grp + 1) * p.group <= p.ntiles_n ? p.group : p.ntiles_n - grp * p.group;      // (the last group may be short)
-    const int mtile = (int)(lg / (unsigned)gsz);
-    const int ntile = grp * p.group + (int)(lg - (unsigned)mtile * (unsigned)gsz);
-    const int tw = mtile % p.tiles_w;
-    const int th = (mtile / p.tiles_w) % p.tiles_h;
-    const int img = mtile / (p.tiles_w * p.tiles_h);
-    const int h0 = th * 4 * p.tr, w0 = tw * 4 * p.tc;
-    const int n0 = ntile * W4_NT;
+    const int total = mtiles * p.ntiles_n;
+    const int nx = ((gridDim.x & 7u) == 0u && (total & 7) == 0) ? 8 : 1;
+    const int per_x = total / nx, nbx = (int)gridDim.x / nx;
+    const int item_base = ((int)blockIdx.x % nx) * per_x;
+    int item_l = (int)blockIdx.x / nx;                 // index within the XCD's run; the block's items: item_l, item_l + nbx, ...
     const int ntl = p.tr * p.tc;                       // tiles in use (MFMA rows beyond them compute on tile 0's data, never written)
     const int PC = 4 * p.tc + 2;                       // patch columns
     const int M = p.cred / 16;                         // 16-channel steps
@@ -120,35 +112,59 @@ __global__ void __launch_bounds__(W4_THREADS, 1) conv3_wino4_kernel(Wino4Args p)
     // lanes of a pixel read one contiguous 64-byte piece -- a load instruction touches 16 cache lines, not 64 (measured: the
     // line look-ups of 16-byte pieces scattered over 64 pixels were what the loop waited for)
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.u_bytes, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     const int sc = t & 3;
-    unsigned pgo[2][6];
-    unsigned inimg[2] = {0u, 0u};
+    int sstr[2], sspc[2];
+    bool ssv[2];
     int swo[2][2];      // [task][buffer]
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int strip = (t >> 2) + 64 * j;
-        const bool sv = strip < p.tr * PC;
-        const int str = sv ? strip / PC : 0, spc = sv ? strip - str * PC : 0;
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            const int gh = h0 - 1 + 4 * str + r, gw = w0 - 1 + spc;
-            const bool ok = sv && gh >= 0 && gh < p.h && gw >= 0 && gw < p.w;
-            pgo[j][r] = ok ? (unsigned)(((((long long)img * p.in_hp + gh) * p.in_wp + gw) * p.ldi + 4 * sc) * 4) : OOB;
-            inimg[j] |= (ok ? 1u : 0u) << r;
-        }
+        ssv[j] = strip < p.tr * PC;
+        sstr[j] = ssv[j] ? strip / PC : 0;
+        sspc[j] = ssv[j] ? strip - sstr[j] * PC : 0;
         // LDS slot of (quad, tile row, row a, pixel column x): quad * QPS + tr * TRS + (4a + (x & 3)) * RL + (x >> 2): the lanes of a
         // fragment read (consecutive tiles: columns 4 apart) and of a strip store (four quads of consecutive columns; QPS = 1 mod 16)
         // both spread over the banks
-        const int v = (sc * p.qps + str * p.trs + (spc & 3) * W4_RL + (spc >> 2)) * 4;
-        swo[j][0] = sv ? v : 2 * W4_VB_F + (t & 3) * 4;
-        swo[j][1] = sv ? v + W4_VB_F : 2 * W4_VB_F + (t & 3) * 4;
+        const int v = (sc * p.qps + sstr[j] * p.trs + (sspc[j] & 3) * W4_RL + (sspc[j] >> 2)) * 4;
+        swo[j][0] = ssv[j] ? v : 2 * W4_VB_F + (t & 3) * 4;
+        swo[j][1] = ssv[j] ? v + W4_VB_F : 2 * W4_VB_F + (t & 3) * 4;
     }
+    // per work item: where it is, and the global offsets of the thread's strips / weight fragments
+    struct Item { int img, h0, w0, n0, mtile; };
+    unsigned pgb[2];        // byte offset of the strip's top pixel (row h0 - 1 + 4 str; may lie above the image: wraps, never used then)
+    unsigned inimg[2];      // bit r: row r of the strip is an image pixel (else zero padding)
+    unsigned ubo;
+    const int rowpitch = p.in_wp * p.ldi * 4;
+    auto setup = [&](int il, Item& it) {
+        const int W = item_base + il;
+        const int ntile = W / mtiles;
+        it.mtile = W - ntile * mtiles;
+        const int tw = it.mtile % p.tiles_w;
+        const int th = (it.mtile / p.tiles_w) % p.tiles_h;
+        it.img = it.mtile / (p.tiles_w * p.tiles_h);
+        it.h0 = th * 4 * p.tr; it.w0 = tw * 4 * p.tc;
+        it.n0 = ntile * W4_NT;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int gh0 = it.h0 - 1 + 4 * sstr[j], gw = it.w0 - 1 + sspc[j];
+            const bool cok = ssv[j] && gw >= 0 && gw < p.w;
+            pgb[j] = (unsigned)(((((long long)it.img * p.in_hp + gh0) * p.in_wp + gw) * p.ldi + 4 * sc) * 4);
+            inimg[j] = 0u;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) inimg[j] |= ((cok && gh0 + r >= 0 && gh0 + r < p.h) ? 1u : 0u) << r;
+        }
+        ubo = it.n0 + li < p.nout ? (unsigned)(((it.n0 + li) * 8 + hh * 4) * 4) : OOB;
+    };
     float4 sreg[2][6];
     auto issue_strip = [&](int m, int j) {
         const int soff = (m < M ? m : M - 1) * 64;
+        // (one offset register per strip: the rows are formed on the way, a row outside the image takes the out-of-range offset.
+        // NOT in the scalar offset: that one is added after the range check, and the top row of the top tiles wraps below zero.)
 #pragma unroll
-        for (int r = 0; r < 6; ++r) sreg[j][r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rin, pgo[j][r], soff, 0));
+        for (int r = 0; r < 6; ++r)
+            sreg[j][r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rin, ((inimg[j] >> r) & 1u) ? pgb[j] + (unsigned)(r * rowpitch) : OOB, soff, 0));
     };
     // B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1] down the strip; half 0 = rows 0..2,
     // half 1 = rows 3..5 (dealt to two MFMA blocks)
@@ -188,18 +204,12 @@ __global__ void __launch_bounds__(W4_THREADS, 1) conv3_wino4_kernel(Wino4Args p)
     int rbase[2];       // [8-channel half kh]: quad 2 kh + hh
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) rbase[kh] = ((2 * kh + hh) * p.qps + ttr * p.trs + ttc) * 4 + 3 * ra * W4_AROW_F;
-    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.u_bytes, 0x00020000);
-    const unsigned ubo = n0 + li < p.nout ? (unsigned)(((n0 + li) * 8 + hh * 4) * 4) : OOB;
     const int upos = p.npad * 32;                      // bytes of one position of one 8-channel step
     const int ustep = 36 * upos;
     const int ubase = (ra * 18 + rb * 3) * upos;
 
     f32x16 acc[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
-    float4 bq[6][3];                                    // [region r = 2 ai + kh][bi]
+    float4 bq[6][3];                                    // [block r = 2 ai + kh][bi]
     auto load_b = [&](int m, int r, int bi) {
         const int soff = (2 * (m < M ? m : M - 1) + (r & 1)) * ustep + ubase + ((r >> 1) * 6 + bi) * upos;
         bq[r][bi] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ru, ubo, soff, 0));
@@ -212,7 +222,9 @@ __global__ void __launch_bounds__(W4_THREADS, 1) conv3_wino4_kernel(Wino4Args p)
         acc[k] = mfma32(a.w, bq[r][bi].w, acc[k]);
     };
 
-    // the loop, instantiated per column half RB of the quadrant (compile-time LDS offsets and transform constants)
+    // the loop over the 16-channel steps of one work item, instantiated per column half RB of the quadrant (compile-time LDS offsets
+    // and transform constants).  On entry: the strips of step 0 are in buffer 0 and visible, those of step 1 and the weights of
+    // step 0 are in flight (in that order).
     auto run = [&](auto RBc) {
         constexpr int RB = decltype(RBc)::value;
         // the five pixel columns j = RB .. RB + 4 of the tile's six: float offsets of (phase j & 3, quad column j >> 2)
@@ -240,20 +252,6 @@ __global__ void __launch_bounds__(W4_THREADS, 1) conv3_wino4_kernel(Wino4Args p)
         };
 
         float4 ev[5], av[2][3];
-        // (the order of the loads in flight at loop entry is the steady state's -- strips of the next step, then the weight
-        // fragments: the compiler's s_waitcnt counts are the minimum over both ways into the loop)
-        issue_strip(0, 0);
-        issue_strip(0, 1);
-        __syncthreads();                // coef[] visible
-#pragma unroll
-        for (int j = 0; j < 2; ++j) { commit_strip(0, j, swo[j][0], 0); commit_strip(0, j, swo[j][0], 1); }
-        issue_strip(1, 0);
-        issue_strip(1, 1);
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int bi = 0; bi < 3; ++bi) load_b(0, r, bi);
-        __syncthreads();
         read_row(0, 0, ev);
         finish_row(ev, av[0]);
 
@@ -297,45 +295,49 @@ __global__ void __launch_bounds__(W4_THREADS, 1) conv3_wino4_kernel(Wino4Args p)
         }
         if (m < M) step(wino_const<0>{}, m);
     };
-    if (rb == 0) run(wino_const<0>{});
-    else run(wino_const<1>{});
-    __syncthreads();            // every wave is done with the strip buffers: the epilogue reuses them
 
-    // ---- epilogue.  C/D layout of a 32x32 accumulator: column = lane & 31 (output channel), row = (e & 3) + 8 * (e >> 2) + 4 * hh (tile).
-    //   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]:  y = A^T m A per (tile, channel)
-    float* ms = smem;                                             // [position][tile][33]
-    float* red = smem + W4_MS_F;
-    const int ecol = t & 31, eg = t >> 5;                         // thread = (channel ecol of the half, tiles eg, eg + 8, eg + 16, eg + 24)
+    // ---- epilogue pieces.  C/D layout of a 32x32 accumulator: column = lane & 31 (output channel), row = (e & 3) + 8 * (e >> 2) + 4 * hh
+    // (tile).  Four rounds of eight tiles (e >> 2 = round) through a 38 KB staging area in buffer 1 -- buffer 0 is free for the next
+    // item's first strips meanwhile.   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]:  y = A^T m A per (tile, channel)
+    float* ms = smem + W4_VB_F;                                   // [position][8 tiles][33]
+    float* red = smem + 2 * W4_VB_F;                              // (the spare area) [sum | sumsq][tile group][32]
     float ssum = 0.f, ssq = 0.f;
+    auto epilogue_round = [&](auto QC, const Item& it) {
+        constexpr int q = decltype(QC)::value;
+        // (the thread's coordinates pass through an empty asm: everything derived from them -- LDS addresses, the tile's row and
+        // column by integer division -- is recomputed here, per round, instead of being hoisted out of the item loop and held in
+        // registers, or spilled, across the step loop: measured 130 spills, reloaded behind s_waitcnt vmcnt(0))
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+        const int ecol = tt & 31, eg = tt >> 5;                   // thread = (channel ecol, tile eg of the round)
+        const int wli = tt & 31, whh = (tt >> 5) & 1;
+        {
+            float* wdst = ms + (4 * whh) * W4_MS_LD + wli;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const int pos = (3 * ra + k / 3) * 6 + 3 * rb + k % 3;
+            for (int k = 0; k < 9; ++k) {
+                const int pos = (3 * ra + k / 3) * 6 + 3 * rb + k % 3;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int tl = (e & 3) + 8 * (e >> 2) + 4 * hh;
-            ms[(pos * 32 + tl) * W4_MS_LD + li] = acc[k][e];
+                for (int e4 = 0; e4 < 4; ++e4) wdst[(pos * 8 + e4) * W4_MS_LD] = acc[k][4 * q + e4];
+            }
         }
-    }
-    __syncthreads();
-    const int j = n0 + ecol;
-    const bool jok = j < p.nout;
-#pragma unroll 1
-    for (int r = 0; r < 4; ++r) {
-        const int tl = eg + 8 * r;
+        __syncthreads();
+        const int j = it.n0 + ecol;
+        const bool jok = j < p.nout;
+        const int tl = 8 * q + eg;
         const int tr2 = tl / p.tc, tc2 = tl - tr2 * p.tc;
         float c[4][6];      // A^T m: rows i, columns b
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
-            float m[6];
+            float mm[6];
 #pragma unroll
-            for (int a = 0; a < 6; ++a) m[a] = ms[((a * 6 + b) * 32 + tl) * W4_MS_LD + ecol];
-            const float pp = m[1] + m[2], qq = m[1] - m[2], rr = m[3] + m[4], uu = m[3] - m[4];
-            c[0][b] = m[0] + pp + rr;
+            for (int a = 0; a < 6; ++a) mm[a] = ms[((a * 6 + b) * 8 + eg) * W4_MS_LD + ecol];
+            const float pp = mm[1] + mm[2], qq = mm[1] - mm[2], rr = mm[3] + mm[4], uu = mm[3] - mm[4];
+            c[0][b] = mm[0] + pp + rr;
             c[1][b] = fmaf(2.f, uu, qq);
             c[2][b] = fmaf(4.f, rr, pp);
-            c[3][b] = fmaf(8.f, uu, qq) + m[5];
+            c[3][b] = fmaf(8.f, uu, qq) + mm[5];
         }
-        const int oh = h0 + 4 * tr2, ow = w0 + 4 * tc2;
+        const int oh = it.h0 + 4 * tr2, ow = it.w0 + 4 * tc2;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float pp = c[i][1] + c[i][2], qq = c[i][1] - c[i][2], rr = c[i][3] + c[i][4], uu = c[i][3] - c[i][4];
@@ -343,7 +345,7 @@ __global__ void __launch_bounds__(W4_THREADS, 1) conv3_wino4_kernel(Wino4Args p)
 #pragma unroll
             for (int jx = 0; jx < 4; ++jx) {
                 if (jok && tl < ntl && oh + i < p.h && ow + jx < p.w) {
-                    float* dst = p.out + (((long long)img * p.h + oh + i) * p.w + ow + jx) * p.ldo + j;
+                    float* dst = p.out + (((long long)it.img * p.h + oh + i) * p.w + ow + jx) * p.ldo + j;
                     float val = yv[jx];
                     if (p.accumulate) val += *dst;
                     *dst = val;
@@ -352,21 +354,95 @@ __global__ void __launch_bounds__(W4_THREADS, 1) conv3_wino4_kernel(Wino4Args p)
                 }
             }
         }
-    }
-    if (p.stats != nullptr) {
-        red[(0 * 8 + eg) * 32 + ecol] = ssum;
-        red[(1 * 8 + eg) * 32 + ecol] = ssq;
-        __syncthreads();
-        if (t < 2 * W4_NT) {
-            const int which = t / W4_NT, col = t - which * W4_NT, j2 = n0 + col;
-            if (j2 < p.nout) {
-                float v = 0.f;
+        __syncthreads();            // the staging area is free for the next round
+    };
+
+    // the loads in flight when the step loop is entered, in the ORDER the loop keeps them in (strips of step 1, task 0 then task 1, then
+    // the weight fragments block by block): the compiler's s_waitcnt counts are the minimum over all ways into the loop, and it may
+    // reorder independent loads -- hence the fences
+    auto first_strips = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        issue_strip(1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_strip(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto first_weights = [&]() {
 #pragma unroll
-                for (int g = 0; g < 8; ++g) v += red[(which * 8 + g) * 32 + col];
-                p.stats[((long long)mtile * 2 + which) * p.nout + j2] = v;
+        for (int r = 0; r < 6; ++r) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int bi = 0; bi < 3; ++bi) load_b(0, r, bi);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- the block's items
+    const int n_items = item_l < per_x ? (per_x - item_l + nbx - 1) / nbx : 0;
+    if (n_items == 0) return;
+    Item cur_it;
+    setup(item_l, cur_it);
+    issue_strip(0, 0);
+    issue_strip(0, 1);
+    __syncthreads();                // coef[] visible
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { commit_strip(0, j, swo[j][0], 0); commit_strip(0, j, swo[j][0], 1); }
+    first_strips();
+    first_weights();
+    // (the column half RB of the wave's quadrant is a compile-time constant of everything below: ONE branch per kernel.  Inside the
+    // item loop it made the register allocator store and reload the 120 registers of loads in flight around it, per item, behind
+    // s_waitcnt vmcnt(0).)
+    auto items = [&](auto RBc) {
+    for (int k = 0; k < n_items; ++k) {
+#pragma unroll
+        for (int kk = 0; kk < 9; ++kk)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[kk][e] = 0.f;
+        __syncthreads();            // the strips of step 0 (buffer 0) are visible
+        if (p.trace != nullptr && t == 0) p.trace[((long long)blockIdx.x * 64 + (k & 63)) * 4 + 0] = clock64();
+        run(RBc);
+        if (p.trace != nullptr && t == 0) p.trace[((long long)blockIdx.x * 64 + (k & 63)) * 4 + 1] = clock64();
+        __syncthreads();            // every wave is done with the strip buffers
+        const Item done = cur_it;
+        const bool more = k + 1 < n_items;
+        if (more) {                 // the next item's first loads fly while this one leaves
+            item_l += nbx;
+            setup(item_l, cur_it);
+            issue_strip(0, 0);
+            issue_strip(0, 1);
+        }
+        ssum = 0.f; ssq = 0.f;
+        epilogue_round(wino_const<0>{}, done);
+        epilogue_round(wino_const<1>{}, done);
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { commit_strip(0, j, swo[j][0], 0); commit_strip(0, j, swo[j][0], 1); }
+            first_strips();
+        }
+        epilogue_round(wino_const<2>{}, done);
+        epilogue_round(wino_const<3>{}, done);
+        if (more) first_weights();      // (L2 hits; 72 registers the epilogue needs for itself)
+        if (p.stats != nullptr) {
+            int tt = t;
+            asm volatile("" : "+v"(tt));
+            red[(0 * 8 + (tt >> 5)) * 32 + (tt & 31)] = ssum;
+            red[(1 * 8 + (tt >> 5)) * 32 + (tt & 31)] = ssq;
+            __syncthreads();
+            if (tt < 2 * W4_NT) {
+                const int which = tt / W4_NT, col = tt - which * W4_NT, j2 = done.n0 + col;
+                if (j2 < p.nout) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) v += red[(which * 8 + g) * 32 + col];
+                    p.stats[((long long)done.mtile * 2 + which) * p.nout + j2] = v;
+                }
             }
         }
+        if (p.trace != nullptr && t == 0) p.trace[((long long)blockIdx.x * 64 + (k & 63)) * 4 + 2] = clock64();
     }
+    };
+    if (rb == 0) items(wino_const<0>{});
+    else items(wino_const<1>{});
 }
 
 // U = G w G^T per (input channel, output channel) pair, G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1],

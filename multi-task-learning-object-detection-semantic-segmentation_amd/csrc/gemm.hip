@@ -14,6 +14,7 @@
 // 32-63 (for A and B alike).  The weight tile sits in LDS as [32][BN+1] and is read with conflict-free ds_read_b32.
 // The next tile's global loads are issued before the current tile's MFMAs (register prefetch).
 #include "common.h"
+#include <vector>
 
 #include <stdlib.h>
 
@@ -1595,7 +1596,8 @@ bool conv3_wino4_takes(int n, int h, int w, int cred, int nout) {
     if (!wino4_geometry(h, w, &g)) return false;
     if ((long long)36 * cred * cdiv(nout, W4_NT) * W4_NT * 4 >= (1LL << 31)) return false;
     if (e != nullptr && e[0] == '1') return true;
-    return false;
+    // automatic: where every CU gets a few work items (pixel tile x 32-channel tile) -- the decoder conv of the full-size models
+    return (long long)n * g.tiles_h * g.tiles_w * cdiv(nout, W4_NT) >= 2048;
 }
 
 int conv3_wino4_launch(ssdseg_ctx* ctx, const Conv3TArgs& a, const float* w, int cin, int cout, int mode) {
@@ -1619,7 +1621,7 @@ int conv3_wino4_launch(ssdseg_ctx* ctx, const Conv3TArgs& a, const float* w, int
     p.in_hp = a.in_hp ? a.in_hp : a.h; p.in_wp = a.in_hp ? a.in_wp : a.w;
     p.in_bytes = (unsigned)(((((long long)(a.n - 1) * p.in_hp + a.h - 1) * p.in_wp + a.w - 1) * a.ldi + a.cred) * 4);
     p.u_bytes = (unsigned)ubytes;
-    { const char* e = getenv("SSDSEG_W4_GROUP"); p.group = e ? atoi(e) : 1; if (p.group < 1) p.group = 1; if (p.group > p.ntiles_n) p.group = p.ntiles_n; }
+    p.trace = nullptr;
     const size_t lds = wino4_lds_floats(a.cred) * sizeof(float);
     static size_t configured = 0;
     if (lds > configured) {
@@ -1632,15 +1634,39 @@ int conv3_wino4_launch(ssdseg_ctx* ctx, const Conv3TArgs& a, const float* w, int
     // flops EXECUTED on the MFMA pipe: 36 positions x (m / 16) tiles x 2 cred nout = 4.5 m cred nout -- a quarter of the direct sum's 18
     const double cost_flops = 4.5 * m * a.cred * a.nout;
     const int mtiles = a.n * g.tiles_h * g.tiles_w;
+    // persistent blocks: one per CU (154 KB of LDS each), a multiple of 8 so that every XCD walks one contiguous run of the items
+    const long long items = (long long)mtiles * p.ntiles_n;
+    int nblocks = ctx->num_cus;
+    if (const char* e = getenv("SSDSEG_W4_BLOCKS")) nblocks = atoi(e) > 0 ? atoi(e) : nblocks;
+    if (nblocks > items) nblocks = (int)items;
+    if (nblocks >= 8 && items % 8 == 0) nblocks -= nblocks % 8;
+    if (getenv("SSDSEG_W4_TRACE") != nullptr) { SSDSEG_HIP(hipMalloc((void**)&p.trace, (size_t)nblocks * 64 * 4 * 8)); SSDSEG_HIP(hipMemset(p.trace, 0, (size_t)nblocks * 64 * 4 * 8)); }
     const bool with_view = a.cs != nullptr || a.act != SSDSEG_ACT_NONE;
     char kbuf[64];
     snprintf(kbuf, sizeof(kbuf), "conv3_wino4_kernel<%s> [%s]", with_view ? "true" : "false", mode ? "bwd_data" : "fwd");
     const char* kname = ctx->timing ? ssdseg_intern(kbuf) : "";
     if (with_view)
-        SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, conv3_wino4_kernel<true>, dim3((unsigned)(mtiles * p.ntiles_n)), dim3(W4_THREADS), lds, p);
+        SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, conv3_wino4_kernel<true>, dim3((unsigned)nblocks), dim3(W4_THREADS), lds, p);
     else
-        SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, conv3_wino4_kernel<false>, dim3((unsigned)(mtiles * p.ntiles_n)), dim3(W4_THREADS), lds, p);
+        SSDSEG_LAUNCH_NAMED(ctx, kname, cost_bytes, cost_flops, conv3_wino4_kernel<false>, dim3((unsigned)nblocks), dim3(W4_THREADS), lds, p);
     SSDSEG_LAUNCH_CHECK();
+    if (p.trace != nullptr) {       // measurement only: synchronous, prints to stderr
+        std::vector<unsigned long long> h((size_t)nblocks * 64 * 4);
+        SSDSEG_HIP(hipStreamSynchronize(ctx->stream));
+        SSDSEG_HIP(hipMemcpy(h.data(), p.trace, h.size() * 8, hipMemcpyDeviceToHost));
+        SSDSEG_HIP(hipFree(p.trace));
+        const int per = (int)((items + nblocks - 1) / nblocks) < 64 ? (int)((items + nblocks - 1) / nblocks) : 64;
+        for (int b : {0, 1, nblocks / 2, nblocks - 1}) {
+            double loop = 0, epi = 0;
+            for (int k = 0; k < per; ++k) {
+                loop += (double)(h[((size_t)b * 64 + k) * 4 + 1] - h[((size_t)b * 64 + k) * 4 + 0]);
+                epi += (double)(h[((size_t)b * 64 + k) * 4 + 2] - h[((size_t)b * 64 + k) * 4 + 1]);
+            }
+            const double gap = per > 1 ? ((double)(h[((size_t)b * 64 + per - 1) * 4 + 0] - h[((size_t)b * 64) * 4 + 0]) - (loop - (double)(h[((size_t)b * 64 + per - 1) * 4 + 1] - h[((size_t)b * 64 + per - 1) * 4 + 0])) ) / (per - 1) : 0;
+            fprintf(stderr, "w4 trace block %3d: %d items, loop %.0f clk/item (%.0f per 16-channel step), loop end -> item end %.0f, loop end -> next loop start %.0f\n", b, per,
+                    loop / per, loop / per / (a.cred / 16), epi / per, gap);
+        }
+    }
     return 0;
 }
 
