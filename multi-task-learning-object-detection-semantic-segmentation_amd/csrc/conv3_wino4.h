@@ -71,11 +71,47 @@ struct Wino4Args {
     unsigned long long* trace;   // measurement only (SSDSEG_W4_TRACE): per block and item, the clock at loop start / loop end / item end
 };
 
-struct w4f4 {   // (helpers on float4: the compiler forms v_pk_fma_f32 / v_pk_add_f32 from them)
-    static __device__ __forceinline__ float4 fma(float s, float4 a, float4 b) { return make_float4(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z), fmaf(s, a.w, b.w)); }
-    static __device__ __forceinline__ float4 add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-    static __device__ __forceinline__ float4 sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
-};
+// float4 as two PACKED pairs.  What scripts/micro/mfma_filler.hip measured on gfx950 (profiles/r03_mfma_f32_filler_cost.txt): beside
+// v_mfma_f32_32x32x2_f32 NOTHING of the vector ALU hides -- a loop of chained MFMAs runs 64 cycles per MFMA, and every v_fma_f32 /
+// v_add_u32 / v_mov_b32 placed between two of them adds ~4.4 cycles (one wave per SIMD; ~2.2 with two), plus ~10 cycles per MFMA ->
+// VALU -> MFMA turn-around, whatever the instruction; a v_pk_fma_f32 costs the same slot as a v_fma_f32 and does twice the work.
+// (LDS reads, scalar instructions and s_nop are nearly free; buffer loads ~8 cycles when at most one sits in a gap.)  The fp32 MFMA
+// and the vector ALU behave as ONE pipe.  Hence: (1) the transforms are v_pk_*_f32, and in INLINE ASSEMBLY because hipcc splits
+// packed f32 instructions back into single-lane ones wherever an MFMA is near (a peephole tuned for the 16-bit MFMAs, whose shadow
+// does hide single-lane work); (2) the vector work of a block of 12 MFMAs sits in ONE cluster behind the block, not spread over
+// its gaps (six turn-arounds per step instead of seventy-two).
+typedef float w4v2 __attribute__((ext_vector_type(2)));
+struct w4q { w4v2 lo, hi; };
+__device__ __forceinline__ w4q w4_from(float4 v) { return w4q{w4v2{v.x, v.y}, w4v2{v.z, v.w}}; }
+__device__ __forceinline__ float4 w4_to(w4q v) { return make_float4(v.lo[0], v.lo[1], v.hi[0], v.hi[1]); }
+#define W4_PK3(name, text)                                                                                        \
+    __device__ __forceinline__ w4q name(w4q a, w4q b) {                                                             \
+        w4q d;                                                                                                      \
+        asm(text : "=v"(d.lo) : "v"(a.lo), "v"(b.lo));                                                             \
+        asm(text : "=v"(d.hi) : "v"(a.hi), "v"(b.hi));                                                             \
+        return d;                                                                                                   \
+    }
+W4_PK3(w4_add, "v_pk_add_f32 %0, %1, %2")                                         // a + b
+W4_PK3(w4_sub, "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]")               // a - b
+W4_PK3(w4_fma4, "v_pk_fma_f32 %0, %1, 4.0, %2 op_sel_hi:[1,0,1]")                 // 4 a + b
+W4_PK3(w4_fmam4, "v_pk_fma_f32 %0, %1, -4.0, %2 op_sel_hi:[1,0,1]")               // -4 a + b
+W4_PK3(w4_fma2, "v_pk_fma_f32 %0, %1, 2.0, %2 op_sel_hi:[1,0,1]")                 // 2 a + b
+W4_PK3(w4_fmam2, "v_pk_fma_f32 %0, %1, -2.0, %2 op_sel_hi:[1,0,1]")               // -2 a + b
+#undef W4_PK3
+// one column of B^T d from the six values down it (B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0;
+// 0 4 0 -5 0 1]): rows 0..2 from d0..d4, rows 3..5 from d1..d5; six packed-pair operations (12 instructions) each
+__device__ __forceinline__ void w4_bt_lo(w4q d0, w4q d1, w4q d2, w4q d3, w4q d4, w4q* o) {
+    const w4q t1 = w4_fmam4(d2, d4), t2 = w4_fmam4(d1, d3);       // d4 - 4 d2, d3 - 4 d1
+    o[0] = w4_fma4(d0, w4_sub(t1, d2));                           // 4 d0 - 5 d2 + d4
+    o[1] = w4_add(t1, t2);
+    o[2] = w4_sub(t1, t2);
+}
+__device__ __forceinline__ void w4_bt_hi(w4q d1, w4q d2, w4q d3, w4q d4, w4q d5, w4q* o) {
+    const w4q t3 = w4_sub(d4, d2), t4 = w4_sub(d3, d1);
+    o[0] = w4_fma2(t4, t3);                                       // (d4 - d2) + 2 (d3 - d1)
+    o[1] = w4_fmam2(t4, t3);
+    o[2] = w4_fmam4(t4, w4_sub(d5, d3));                          // 4 d1 - 5 d3 + d5
+}
 
 template <bool VIEW>
 __global__ void __launch_bounds__(W4_THREADS, 1) conv3_wino4_kernel(Wino4Args p) {
@@ -166,10 +202,10 @@ __global__ void __launch_bounds__(W4_THREADS, 1) conv3_wino4_kernel(Wino4Args p)
         for (int r = 0; r < 6; ++r)
             sreg[j][r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rin, ((inimg[j] >> r) & 1u) ? pgb[j] + (unsigned)(r * rowpitch) : OOB, soff, 0));
     };
-    // B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1] down the strip; half 0 = rows 0..2,
-    // half 1 = rows 3..5 (dealt to two MFMA blocks)
-    auto commit_strip = [&](int m, int j, int boff, int half) {
-        float4 d[6];
+    // the row half of the input transform down a strip: half 0 = rows 0..2 of B^T d, half 1 = rows 3..5 (dealt to two MFMA blocks);
+    // computed into registers here, stored to LDS by the caller (one ds_write_b128 per MFMA gap)
+    auto commit_compute = [&](int m, int j, int half, w4q* o) {
+        w4q d[6];
         if (VIEW) {
             const int c0 = (m < M ? m : M - 1) * 16 + 4 * sc;
             const float4 cs = ld4(coef + c0), ct = ld4(coef + cld + c0);
@@ -177,24 +213,21 @@ __global__ void __launch_bounds__(W4_THREADS, 1) conv3_wino4_kernel(Wino4Args p)
             for (int r = 0; r < 6; ++r) {
                 const float keep = ((inimg[j] >> r) & 1u) ? 1.f : 0.f;      // zero padding AFTER the view
                 const float4 v = view_affine4(sreg[j][r], cs, ct, alo, ahi);
-                d[r] = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep);
+                d[r] = w4_from(make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep));
             }
         } else {
 #pragma unroll
-            for (int r = 0; r < 6; ++r) d[r] = sreg[j][r];
+            for (int r = 0; r < 6; ++r) d[r] = w4_from(sreg[j][r]);
         }
-        float* dst = smem + boff;
-        if (half == 0) {
-            const float4 t1 = w4f4::fma(-4.f, d[2], d[4]), t2 = w4f4::fma(-4.f, d[1], d[3]);
-            st4(dst + 0 * W4_AROW_F, w4f4::fma(4.f, d[0], w4f4::fma(-5.f, d[2], d[4])));
-            st4(dst + 1 * W4_AROW_F, w4f4::add(t1, t2));
-            st4(dst + 2 * W4_AROW_F, w4f4::sub(t1, t2));
-        } else {
-            const float4 t3 = w4f4::sub(d[4], d[2]), t4 = w4f4::sub(d[3], d[1]);
-            st4(dst + 3 * W4_AROW_F, w4f4::fma(2.f, t4, t3));
-            st4(dst + 4 * W4_AROW_F, w4f4::fma(-2.f, t4, t3));
-            st4(dst + 5 * W4_AROW_F, w4f4::fma(4.f, d[1], w4f4::fma(-5.f, d[3], d[5])));
-        }
+        if (half == 0) w4_bt_lo(d[0], d[1], d[2], d[3], d[4], o);
+        else w4_bt_hi(d[1], d[2], d[3], d[4], d[5], o);
+    };
+    auto commit_store = [&](int boff, int half, int i, const w4q* o) { st4(smem + boff + (3 * half + i) * W4_AROW_F, w4_to(o[i])); };
+    auto commit_strip = [&](int m, int j, int boff, int half) {      // (outside the step loop)
+        w4q o[3];
+        commit_compute(m, j, half, o);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) commit_store(boff, half, i, o);
     };
 
     // ---- MFMA role: wave = quadrant (ra, rb) of the 6 x 6 position grid; lane = (tile, 4-channel quad of an 8-channel half step)
@@ -214,79 +247,86 @@ __global__ void __launch_bounds__(W4_THREADS, 1) conv3_wino4_kernel(Wino4Args p)
         const int soff = (2 * (m < M ? m : M - 1) + (r & 1)) * ustep + ubase + ((r >> 1) * 6 + bi) * upos;
         bq[r][bi] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ru, ubo, soff, 0));
     };
-    auto mfmas = [&](const float4 a, int r, int bi) {
-        const int k = (r >> 1) * 3 + bi;
-        acc[k] = mfma32(a.x, bq[r][bi].x, acc[k]);
-        acc[k] = mfma32(a.y, bq[r][bi].y, acc[k]);
-        acc[k] = mfma32(a.z, bq[r][bi].z, acc[k]);
-        acc[k] = mfma32(a.w, bq[r][bi].w, acc[k]);
-    };
-
     // the loop over the 16-channel steps of one work item, instantiated per column half RB of the quadrant (compile-time LDS offsets
     // and transform constants).  On entry: the strips of step 0 are in buffer 0 and visible, those of step 1 and the weights of
     // step 0 are in flight (in that order).
     auto run = [&](auto RBc) {
         constexpr int RB = decltype(RBc)::value;
         // the five pixel columns j = RB .. RB + 4 of the tile's six: float offsets of (phase j & 3, quad column j >> 2)
-        auto read_row = [&](int boff, int r, float4* e) {
+        auto read1 = [&](int boff, int r, int jj, w4q* e) {
             const float* src = smem + boff + rbase[r & 1] + (r >> 1) * W4_AROW_F;
-#pragma unroll
-            for (int jj = 0; jj < 5; ++jj) {
-                const int j = RB + jj;
-                e[jj] = ld4(src + ((j & 3) * W4_RL + (j >> 2)) * 4);
-            }
+            const int j = RB + jj;
+            e[jj] = w4_from(ld4(src + ((j & 3) * W4_RL + (j >> 2)) * 4));
         };
         // rows b of B^T applied along the columns: V[a][3RB + 0..2]
-        auto finish_row = [&](const float4* e, float4* v) {
-            if constexpr (RB == 0) {      // e = d0..d4:  b = 0: 4 d0 - 5 d2 + d4;  b = 1, 2: (d4 - 4 d2) +- (d3 - 4 d1)
-                const float4 t1 = w4f4::fma(-4.f, e[2], e[4]), t2 = w4f4::fma(-4.f, e[1], e[3]);
-                v[0] = w4f4::fma(4.f, e[0], w4f4::fma(-5.f, e[2], e[4]));
-                v[1] = w4f4::add(t1, t2);
-                v[2] = w4f4::sub(t1, t2);
-            } else {            // e = d1..d5:  b = 3, 4: (d4 - d2) +- 2 (d3 - d1);  b = 5: 4 d1 - 5 d3 + d5
-                const float4 t3 = w4f4::sub(e[3], e[1]), t4 = w4f4::sub(e[2], e[0]);
-                v[0] = w4f4::fma(2.f, t4, t3);
-                v[1] = w4f4::fma(-2.f, t4, t3);
-                v[2] = w4f4::fma(4.f, e[0], w4f4::fma(-5.f, e[2], e[4]));
-            }
+        auto finish_row = [&](const w4q* e, w4q* v) {
+            if constexpr (RB == 0) w4_bt_lo(e[0], e[1], e[2], e[3], e[4], v);      // e = d0..d4
+            else w4_bt_hi(e[0], e[1], e[2], e[3], e[4], v);                        // e = d1..d5
         };
 
-        float4 ev[5], av[2][3];
-        read_row(0, 0, ev);
+        w4q ev[5], av[2][3], cw[3];
+#pragma unroll
+        for (int jj = 0; jj < 5; ++jj) read1(0, 0, jj, ev);
         finish_row(ev, av[0]);
+        commit_compute(1, 0, 0, cw);          // what block 0 of the first step stores
 
-        // One step = 16 input channels = six MFMA blocks (the quadrant's three rows x two 8-channel halves), everything else dealt
-        // into their shadow: with one wave per SIMD the matrix pipe only stays busy if the other instructions sit BETWEEN the MFMAs,
-        // so every block is one scheduling region with an explicit pattern.  Block r: the columns of block r + 1 are read and turned
-        // into its fragments; blocks 0..3 also transform half a strip each of step m + 1 into buffer `nxt` (last read before the barrier of step
-        // m - 1) and re-issue its loads for step m + 2; the ONE barrier sits before block 5, whose reads are the first of `nxt`.
+        // One step = 16 input channels = six blocks of 12 MFMAs (the quadrant's three rows x two 8-channel halves).  The fp32 MFMA
+        // shares its pipe with the vector ALU (see the note at w4q above), so a block is laid out by hand, gap by gap, every gap
+        // fenced: memory instructions (cheap beside MFMAs) one or two per gap, ALL vector arithmetic in one cluster behind the last
+        // MFMA.  Block r: gaps 0..2 store the strip rows the previous block's cluster computed (blocks 0..3: half a strip task each
+        // of step m + 1, into buffer `nxt`, last read before the barrier of step m - 1); gaps 3..5 read the five columns of block
+        // r + 1's row; the weight fragments of a column tile are re-loaded for the next step right after its four MFMAs (gaps 3, 7,
+        // 11); blocks 1 and 3 re-issue their strip task's six loads for step m + 2 (its registers were consumed by the cluster of
+        // the block before); the cluster turns the columns into block r + 1's fragments and transforms the strip half block r + 1
+        // stores.  The ONE barrier of the step sits in gap 3 of block 5, before its reads -- the first of `nxt`.
         // PH = m & 1 selects the buffers at compile time (the loop is unrolled by two).
         auto step = [&](auto PH, int m) {
             constexpr int ph = decltype(PH)::value;
             constexpr int cur = ph ? W4_VB_F : 0, nxt = ph ? 0 : W4_VB_F;
             auto block = [&](auto RC) {
                 constexpr int r = decltype(RC)::value;
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (r == 5) __syncthreads();       // strips of step m + 1 visible, buffer `cur` free
-                if constexpr (r < 5) read_row(cur, r + 1, ev);
-                else read_row(nxt, 0, ev);
-                if constexpr (r < 4) commit_strip(m + 1, r >> 1, swo[r >> 1][ph ^ 1], r & 1);
-                if constexpr (r == 1 || r == 3) issue_strip(m + 2, r >> 1);
+                constexpr bool stores = r < 4, issues = r == 1 || r == 3;
+                constexpr int tj = r >> 1;                           // the strip task of blocks 0..3
+                auto mf = [&](int g) {
+                    const int bi = g >> 2, k = (r >> 1) * 3 + bi;
+                    const w4q a = av[r & 1][bi];
+                    const float4 b = bq[r][bi];
+                    const float af = (g & 3) == 0 ? a.lo[0] : (g & 3) == 1 ? a.lo[1] : (g & 3) == 2 ? a.hi[0] : a.hi[1];
+                    const float bf = (g & 3) == 0 ? b.x : (g & 3) == 1 ? b.y : (g & 3) == 2 ? b.z : b.w;
+                    acc[k] = mfma32(af, bf, acc[k]);
+                };
+                auto issue1 = [&](int rr) {
+                    const int soff = (m + 2 < M ? m + 2 : M - 1) * 64;
+                    sreg[tj][rr] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rin, ((inimg[tj] >> rr) & 1u) ? pgb[tj] + (unsigned)(rr * rowpitch) : OOB, soff, 0));
+                };
+                auto rd = [&](int jj) {
+                    if constexpr (r < 5) read1(cur, r + 1, jj, ev);
+                    else read1(nxt, 0, jj, ev);
+                };
+#define W4_FENCE __builtin_amdgcn_sched_barrier(0)
+                W4_FENCE;
+                mf(0); if constexpr (stores) commit_store(swo[tj][ph ^ 1], r & 1, 0, cw); W4_FENCE;
+                mf(1); if constexpr (stores) commit_store(swo[tj][ph ^ 1], r & 1, 1, cw); if constexpr (issues) issue1(0); W4_FENCE;
+                mf(2); if constexpr (stores) commit_store(swo[tj][ph ^ 1], r & 1, 2, cw); if constexpr (issues) issue1(1); W4_FENCE;
+                mf(3); load_b(m + 1, r, 0);
+                if constexpr (r == 5) __syncthreads();               // strips of step m + 1 visible, buffer `cur` free
+                rd(0); W4_FENCE;
+                mf(4); rd(1); rd(2); W4_FENCE;
+                mf(5); rd(3); rd(4); W4_FENCE;
+                mf(6); if constexpr (issues) issue1(2); W4_FENCE;
+                mf(7); load_b(m + 1, r, 1); W4_FENCE;
+                mf(8); if constexpr (issues) issue1(3); W4_FENCE;
+                mf(9); if constexpr (issues) issue1(4); W4_FENCE;
+                mf(10); if constexpr (issues) issue1(5); W4_FENCE;
+                mf(11); load_b(m + 1, r, 2);
                 finish_row(ev, av[(r + 1) & 1]);
-#pragma unroll
-                for (int bi = 0; bi < 3; ++bi) { mfmas(av[r & 1][bi], r, bi); load_b(m + 1, r, bi); }
-                __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);          // DS reads first
-#pragma unroll
-                for (int i = 0; i < 12; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, r < 4 ? 5 : 3, 0);      // VALU
-                    if constexpr (r < 4) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);       // DS write
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // VMEM read
-                }
+                if constexpr (r < 3) commit_compute(m + 1, (r + 1) >> 1, (r + 1) & 1, cw);
+                if constexpr (r == 5) commit_compute(m + 2, 0, 0, cw);
+                W4_FENCE;
+#undef W4_FENCE
             };
             block(wino_const<0>{}); block(wino_const<1>{}); block(wino_const<2>{});
             block(wino_const<3>{}); block(wino_const<4>{}); block(wino_const<5>{});
-            __builtin_amdgcn_sched_barrier(0);
         };
         int m = 0;
         for (; m + 2 <= M; m += 2) {
