@@ -517,12 +517,17 @@ def main():
                 "traffic_over_algorithmic": round(traffic / alg_bytes, 3) if traffic else None,
             }
             if name.startswith("conv3_wino"):
-                # Winograd F(2x2, 3x3), fp32: the kernel executes 16 multiply-adds per 2x2 output tile and channel pair where the
-                # direct form has 36.  `achieved` / `frac` above count the flops EXECUTED on the MFMA pipe (a utilisation, <= 1);
-                # the figure by the direct convolution's 18 m cin cout flops -- SURVEY.md 8(d)'s unit -- is reported here.
-                out["roofline"]["algorithm"] = "winograd F(2x2,3x3), fp32 transforms and accumulation"
-                out["roofline"]["direct_equivalent"] = {"flops_per_launch": dom["flops"] / dom["count"] * 2.25, "TFLOP/s": round(tfs * 2.25, 2),
-                                                        "over_peak": round(mfma_frac * 2.25, 4)}
+                # Winograd, fp32: F(2x2,3x3) executes 16 multiply-adds per 2x2 output tile and channel pair (F(4x4,3x3): 36 per 4x4
+                # tile) where the direct form has 36 (144).  `achieved` / `frac` above count the flops EXECUTED on the MFMA pipe (a
+                # utilisation, <= 1); the figure by the direct convolution's 18 m cin cout flops -- SURVEY.md 8(d)'s unit -- is here.
+                f4 = name.startswith("conv3_wino4")
+                ratio = 4.0 if f4 else 2.25
+                out["roofline"]["algorithm"] = ("winograd F(4x4,3x3)" if f4 else "winograd F(2x2,3x3)") + ", fp32 transforms and accumulation"
+                out["roofline"]["direct_equivalent"] = {"flops_per_launch": dom["flops"] / dom["count"] * ratio, "TFLOP/s": round(tfs * ratio, 2),
+                                                        "over_peak": round(mfma_frac * ratio, 4)}
+                # gfx950: the fp32 MFMA and the vector ALU are one pipe (profiles/r03_mfma_f32_filler_cost.txt) -- the transforms'
+                # vector instructions are not hidden behind the MFMAs, they add to them; `frac` is MFMA time / kernel time
+                out["roofline"]["note"] = "fp32 MFMA and VALU share one pipe on gfx950: 1 - frac includes the transform arithmetic"
             ach = achievable_ceiling(bound)
             if ach is not None:
                 # extra context, not the contract's `peak`: what a trivial micro-benchmark sustains on this chip (committed summary)

@@ -66,7 +66,7 @@ struct Wino4Args {
     int trs;             // float4 slots between tile rows in LDS (>= 24 * W4_RL, == tc mod 16)
     int qps;             // float4 slots between 4-channel planes (>= tr * trs, == 1 mod 16, <= W4_QP_MAX)
     int tiles_h, tiles_w, ntiles_n;
-    unsigned in_bytes, u_bytes;
+    unsigned in_bytes, u_bytes, out_bytes;
     int in_hp, in_wp;
     unsigned long long* trace;   // measurement only (SSDSEG_W4_TRACE): per block and item, the clock at loop start / loop end / item end
 };
@@ -149,6 +149,7 @@ __global__ void __launch_bounds__(W4_THREADS, 1) conv3_wino4_kernel(Wino4Args p)
     // line look-ups of 16-byte pieces scattered over 64 pixels were what the loop waited for)
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.u_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     const int sc = t & 3;
     int sstr[2], sspc[2];
@@ -378,22 +379,44 @@ __global__ void __launch_bounds__(W4_THREADS, 1) conv3_wino4_kernel(Wino4Args p)
             c[3][b] = fmaf(8.f, uu, qq) + mm[5];
         }
         const int oh = it.h0 + 4 * tr2, ow = it.w0 + 4 * tc2;
+        // stores: ONE 32-bit lane offset per round (the tile's first pixel, this thread's channel), the pixel of the 4 x 4 patch in the
+        // scalar offset, pixels outside the image take the out-of-range offset -- no branch and no 64-bit address per store (sixteen
+        // exec-masked regions of a dozen instructions each were a seventh of the epilogue; with one wave per SIMD every instruction
+        // of the epilogue is exposed).  Accumulating launches (a gradient added to an existing one) keep the plain path.
+        const bool tok = jok && tl < ntl;
+        const unsigned obase = (unsigned)(((((long long)it.img * p.h + oh) * p.w + ow) * p.ldo + j) * 4);
+        const int opix = p.ldo * 4, orow = p.w * opix;
+        float yv[4][4];
+        bool okp[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float pp = c[i][1] + c[i][2], qq = c[i][1] - c[i][2], rr = c[i][3] + c[i][4], uu = c[i][3] - c[i][4];
-            const float yv[4] = {c[i][0] + pp + rr, fmaf(2.f, uu, qq), fmaf(4.f, rr, pp), fmaf(8.f, uu, qq) + c[i][5]};
+            yv[i][0] = c[i][0] + pp + rr; yv[i][1] = fmaf(2.f, uu, qq); yv[i][2] = fmaf(4.f, rr, pp); yv[i][3] = fmaf(8.f, uu, qq) + c[i][5];
+#pragma unroll
+            for (int jx = 0; jx < 4; ++jx) okp[i][jx] = tok && oh + i < p.h && ow + jx < p.w;
+        }
+        if (p.accumulate) {      // (1: add to what is there; 2: plain store through a 64-bit address -- outputs beyond 2 GiB)
+            for (int i = 0; i < 4; ++i)
+                for (int jx = 0; jx < 4; ++jx)
+                    if (okp[i][jx]) {
+                        float* dst = p.out + (((long long)it.img * p.h + oh + i) * p.w + ow + jx) * p.ldo + j;
+                        *dst = p.accumulate == 1 ? *dst + yv[i][jx] : yv[i][jx];
+                    }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jx = 0; jx < 4; ++jx)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yv[i][jx]), rout, okp[i][jx] ? obase : OOB, i * orow + jx * opix, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int jx = 0; jx < 4; ++jx) {
-                if (jok && tl < ntl && oh + i < p.h && ow + jx < p.w) {
-                    float* dst = p.out + (((long long)it.img * p.h + oh + i) * p.w + ow + jx) * p.ldo + j;
-                    float val = yv[jx];
-                    if (p.accumulate) val += *dst;
-                    *dst = val;
-                    ssum += yv[jx];
-                    ssq = fmaf(yv[jx], yv[jx], ssq);
-                }
+                const float ys = okp[i][jx] ? yv[i][jx] : 0.f;
+                ssum += ys;
+                ssq = fmaf(ys, ys, ssq);
             }
-        }
         __syncthreads();            // the staging area is free for the next round
     };
 

@@ -1621,6 +1621,11 @@ int conv3_wino4_launch(ssdseg_ctx* ctx, const Conv3TArgs& a, const float* w, int
     p.in_hp = a.in_hp ? a.in_hp : a.h; p.in_wp = a.in_hp ? a.in_wp : a.w;
     p.in_bytes = (unsigned)(((((long long)(a.n - 1) * p.in_hp + a.h - 1) * p.in_wp + a.w - 1) * a.ldi + a.cred) * 4);
     p.u_bytes = (unsigned)ubytes;
+    {
+        const long long ob = (((long long)a.n * a.h * a.w - 1) * a.ldo + a.nout) * 4;
+        p.out_bytes = ob < (1LL << 31) ? (unsigned)ob : 0u;
+        if (ob >= (1LL << 31) && !p.accumulate) p.accumulate = 2;      // 32-bit buffer offsets do not reach: plain stores
+    }
     p.trace = nullptr;
     const size_t lds = wino4_lds_floats(a.cred) * sizeof(float);
     static size_t configured = 0;
