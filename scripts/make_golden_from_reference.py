@@ -11,6 +11,12 @@ captured here as data:
   stored as .npz (inputs = constructor kwargs, outputs = every getter's array).
 * model summary: the `model.summary()` *output* stored inside NB03#cell12, parsed into JSON rows
   (layer name, type, output shape, #params, inbound layers) + the three totals.
+* offline evaluators: outputs of executing the reference's `ssdseglib/evaluators.py` functions that are pure NumPy / csv --
+  `_iou_boxes_pred_vs_true` (:6-62) and `average_precision_object_detection` (:65-186) -- on seeded synthetic predictions and
+  ground-truth CSV files.  The module has `import tensorflow as tf` at its top (used only by the PNG reader of
+  `jaccard_iou_semantic_segmentation`, which is NOT executed and stays "parity unpinned"); it is loaded by file path with an EMPTY
+  placeholder module registered under that name for the duration of the load, so that the import statement succeeds.  Nothing
+  of TensorFlow is emulated: the two functions run here never touch `tf`.
 
 Usage: python scripts/make_golden_from_reference.py [/root/reference]
 """
@@ -67,6 +73,73 @@ def dump_free_functions(mod):
                         cx=cx, cy=cy, w=w, h=h, x0=x0, y0=y0, x1=x1, y1=y1)
 
 
+def load_reference_evaluators():
+    import types
+    saved = sys.modules.get("tensorflow")
+    sys.modules["tensorflow"] = types.ModuleType("tensorflow")      # empty: satisfies the module-level import, nothing else
+    try:
+        spec = importlib.util.spec_from_file_location("_ref_evaluators", REF / "ssdseglib" / "evaluators.py")
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        if saved is None:
+            del sys.modules["tensorflow"]
+        else:
+            sys.modules["tensorflow"] = saved
+    return mod
+
+
+def dump_evaluators(mod):
+    """seeded detections of S samples (P boxes each after NMS, label 0 = background) against ground-truth CSV files
+    (label,xmin,ymin,xmax,ymax per row; samples without objects: an empty file)"""
+    import tempfile
+    rng = np.random.default_rng(20240611)
+    S, P, GMAX, classes, bg = 12, 10, 5, [0, 1, 2, 3], 0
+    gt_cnt = rng.integers(0, GMAX + 1, S)
+    gt_cnt[3] = 0                                                    # a sample without ground truth
+    gt = np.zeros((S, GMAX, 5), np.float32)
+    labels = np.zeros((S, P), np.int32)
+    conf = np.round(rng.uniform(0.05, 1.0, (S, P)), 2).astype(np.float32)      # two decimals: ties in the ranking are likely
+    boxes = np.zeros((S, P, 4), np.float32)
+    for s in range(S):
+        for g in range(gt_cnt[s]):
+            x0, y0 = rng.uniform(0, 500), rng.uniform(0, 380)
+            w, h = rng.uniform(20, 140), rng.uniform(20, 100)
+            gt[s, g] = [rng.integers(1, 3), x0, y0, x0 + w, y0 + h]  # classes 1 and 2 only: class 3 never has ground truth
+        for p in range(P):
+            kind = rng.integers(0, 4)
+            if kind == 0 or gt_cnt[s] == 0:                          # a free box with any label (incl. background)
+                x0, y0 = rng.uniform(0, 500), rng.uniform(0, 380)
+                boxes[s, p] = [x0, y0, x0 + rng.uniform(10, 140), y0 + rng.uniform(10, 100)]
+                labels[s, p] = rng.integers(0, 4)
+            else:                                                    # a jittered copy of a ground-truth box, right or wrong label
+                g = rng.integers(0, gt_cnt[s])
+                jit = rng.normal(0, 12.0 if kind == 1 else 3.0, 4)
+                boxes[s, p] = gt[s, g, 1:] + jit
+                labels[s, p] = gt[s, g, 0] if kind != 3 else 1 + (int(gt[s, g, 0]) % 3)
+    out = dict(labels=labels, conf=conf, boxes=boxes, gt=gt, gt_cnt=gt_cnt.astype(np.int32), classes=np.asarray(classes), background=np.int32(bg))
+    with tempfile.TemporaryDirectory() as d, warnings.catch_warnings():
+        warnings.simplefilter("ignore", DeprecationWarning)          # np.trapz under NumPy 2
+        paths = []
+        for s in range(S):
+            path = Path(d) / f"gt_{s}.csv"
+            with open(path, "w", newline="") as f:
+                for g in range(gt_cnt[s]):
+                    f.write(",".join([str(int(gt[s, g, 0]))] + [repr(float(v)) for v in gt[s, g, 1:]]) + "\n")
+            paths.append(str(path))
+        for thr in (0.5, 0.75, 0.3):
+            ap = mod.average_precision_object_detection(labels, conf, boxes, thr, paths, classes, bg)
+            assert sorted(ap) == [1, 2, 3]
+            out[f"ap_{int(thr * 100)}"] = np.asarray([ap[c] for c in (1, 2, 3)], np.float64)
+    # the IoU helper alone: one sample with ground truth, one without
+    s = int(np.argmax(gt_cnt))
+    out["iou_sample"] = np.int32(s)
+    out["iou"] = mod._iou_boxes_pred_vs_true(labels[s], boxes[s], gt[s, :gt_cnt[s], 0].astype(np.int32), gt[s, :gt_cnt[s], 1:])
+    out["iou_empty"] = mod._iou_boxes_pred_vs_true(labels[3], boxes[3], np.zeros((0,), np.int32), np.zeros((0,), np.float32))
+    np.savez_compressed(OUT / "evaluators_ap.npz", **out)
+    print("evaluators:", {k: out[k] for k in ("ap_50", "ap_75", "ap_30")}, "iou", out["iou"].shape, out["iou_empty"].shape)
+
+
 def dump_model_summary():
     nb = json.load(open(REF / "03-multi-task-network-ssdlite-deeplabv3plus-training.ipynb"))
     text = "".join(nb["cells"][12]["outputs"][0]["text"])
@@ -119,4 +192,5 @@ if __name__ == "__main__":
                       boxes_scales=(0.1, 0.8), centers_padding_from_borders_percentage=0.0,
                       additional_square_box=False), (113, 257))
     dump_free_functions(ref_boxes)
+    dump_evaluators(load_reference_evaluators())
     dump_model_summary()

@@ -125,6 +125,37 @@ def test_offline_evaluators_hand_worked(tmp_path):
     assert abs(got[1] - 1.5 / 2.0) < 1e-6 and abs(got[2] - 1.0) < 1e-6 and 0 not in got   # class 1: inter 1.5, total 3.5
 
 
+def test_offline_evaluators_match_the_reference_fixture(tmp_path):
+    """ssdseglib.evaluators against outputs of the REFERENCE's own `_iou_boxes_pred_vs_true` / `average_precision_object_detection`
+    (evaluators.py:6-186, pure NumPy + csv) executed on seeded detections by scripts/make_golden_from_reference.py ->
+    tests/golden/evaluators_ap.npz: 12 samples x 10 boxes after NMS (label 0 = background), 0-5 ground-truth boxes each (one
+    sample with an empty file, class 3 without any ground truth, confidences with ties, several predictions on one ground-truth
+    box -- the reference does not mark boxes as used, so recall and AP can exceed 1: 1.0088 at IoU 0.3).  The segmentation
+    Jaccard reads its masks through TensorFlow in the reference and was not executed: that one stays hand-worked (above)."""
+    import ssdseglib
+    g = np.load(os.path.join(REPO, "tests", "golden", "evaluators_ap.npz"))
+    labels, conf, boxes, gt, cnt = g["labels"], g["conf"], g["boxes"], g["gt"], g["gt_cnt"]
+    paths = []
+    for s in range(labels.shape[0]):
+        path = tmp_path / f"gt_{s}.csv"
+        with open(path, "w", newline="") as f:
+            for k in range(cnt[s]):
+                f.write(",".join([str(int(gt[s, k, 0]))] + [repr(float(v)) for v in gt[s, k, 1:]]) + "\n")
+        paths.append(str(path))
+    classes, bg = [int(c) for c in g["classes"]], int(g["background"])
+    for thr in (0.5, 0.75, 0.3):
+        ap = ssdseglib.evaluators.average_precision_object_detection(labels, conf, boxes, thr, paths, classes, bg)
+        want = g[f"ap_{int(thr * 100)}"]
+        assert sorted(ap) == [1, 2, 3]
+        assert np.allclose([ap[1], ap[2], ap[3]], want, rtol=0, atol=1e-6), (thr, ap, want)
+    assert g["ap_30"][0] > 1.0                       # the quirk is in the fixture, and reproduced
+    s = int(g["iou_sample"])
+    iou = ssdseglib.evaluators._iou_boxes_pred_vs_true(labels[s], boxes[s], gt[s, :cnt[s], 0].astype(np.int32), gt[s, :cnt[s], 1:])
+    assert iou.shape == g["iou"].shape and np.allclose(iou, g["iou"], rtol=0, atol=1e-6)
+    empty = ssdseglib.evaluators._iou_boxes_pred_vs_true(labels[3], boxes[3], np.zeros((0,), np.int32), np.zeros((0,), np.float32))
+    assert empty.shape == g["iou_empty"].shape and not empty.any()
+
+
 def _header_prototypes():
     """{function name: [C parameter type, ...]} parsed from include/ssdseg.h"""
     header = open(os.path.join(REPO, "include", "ssdseg.h")).read()
