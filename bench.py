@@ -559,7 +559,7 @@ def main():
         if world == 1 and args.workload != "backbone":
             out["nms_boxes_per_sec"] = nms_boxes_per_sec(ctx, args.batch)   # the metric's second figure (outside the timed region)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, 12 if args.workload == "backbone" else 3)   # ~10-30 s of host work
+            out["cpu_baseline"] = cpu_baseline(args.workload, 12 if args.workload == "backbone" else 6)   # ~10-30 s of host work (6.5 s per 3 images of the full step on the GPU box)
         print(json.dumps(out), flush=True)
 
     if comm is not None:
