@@ -66,6 +66,7 @@ struct Wino4Args {
     int trs;             // float4 slots between tile rows in LDS (>= 24 * W4_RL, == tc mod 16)
     int qps;             // float4 slots between 4-channel planes (>= tr * trs, == 1 mod 16, <= W4_QP_MAX)
     int tiles_h, tiles_w, ntiles_n;
+    int group;           // channel tiles per group of the work order (1 or 2; divides ntiles_n)
     unsigned in_bytes, u_bytes, out_bytes;
     int in_hp, in_wp;
     unsigned long long* trace;   // measurement only (SSDSEG_W4_TRACE): per block and item, the clock at loop start / loop end / item end
@@ -175,9 +176,15 @@ __global__ void __launch_bounds__(W4_THREADS, 1) conv3_wino4_kernel(Wino4Args p)
     unsigned ubo;
     const int rowpitch = p.in_wp * p.ldi * 4;
     auto setup = [&](int il, Item& it) {
+        // work order: channel tiles in GROUPS of p.group (1 or 2), pixel-tile-major inside a group -- items W and W + 1 are the two
+        // channel tiles of one pixel tile, taken by two CUs of the same XCD at about the same time: the second one's input strips
+        // come from that XCD's L2.  An XCD then holds p.group 1.4 MB slices of U instead of one and streams the input of
+        // 1 / (8 / (ntiles_n / group)) of the pixel tiles: HBM reads of the input drop from ntiles_n x to ntiles_n / group x.
         const int W = item_base + il;
-        const int ntile = W / mtiles;
-        it.mtile = W - ntile * mtiles;
+        const int gsz = p.group * mtiles;
+        const int grp = W / gsz, rem = W - grp * gsz;
+        it.mtile = rem / p.group;
+        const int ntile = grp * p.group + (rem - it.mtile * p.group);
         const int tw = it.mtile % p.tiles_w;
         const int th = (it.mtile / p.tiles_w) % p.tiles_h;
         it.img = it.mtile / (p.tiles_w * p.tiles_h);

@@ -1618,6 +1618,11 @@ int conv3_wino4_launch(ssdseg_ctx* ctx, const Conv3TArgs& a, const float* w, int
     p.tr = g.tr; p.tc = g.tc; p.trs = g.trs;
     p.qps = g.tr * g.trs;
     while ((p.qps & 15) != 1) ++p.qps; p.tiles_h = g.tiles_h; p.tiles_w = g.tiles_w; p.ntiles_n = npad / W4_NT;
+    {
+        const char* ge = getenv("SSDSEG_W4_GROUP");      // (A/B runs) channel tiles per group of the work order
+        p.group = ge != nullptr ? atoi(ge) : 2;
+        if (p.group < 1 || p.ntiles_n % p.group != 0) p.group = 1;
+    }
     p.in_hp = a.in_hp ? a.in_hp : a.h; p.in_wp = a.in_hp ? a.in_wp : a.w;
     p.in_bytes = (unsigned)(((((long long)(a.n - 1) * p.in_hp + a.h - 1) * p.in_wp + a.w - 1) * a.ldi + a.cred) * 4);
     p.u_bytes = (unsigned)ubytes;
