@@ -27,8 +27,10 @@
 //                    right after the MFMAs that consumed it (a whole step of latency cover).  U never touches LDS;
 //   each wave runs   3 rows x 2 halves x 3 positions x 4 = 72 v_mfma_f32_32x32x2_f32 against 30 + 12 LDS instructions.
 // Two LDS buffers of row-transformed strips, ONE barrier per step (before the last of its six MFMA blocks).
-// Blocks are ordered channel-tile-major and dealt to the XCDs in contiguous runs: an XCD works on one 32-channel slice of U
-// (1.4 MB at 304 reduction channels) at a time and keeps it in its L2 (the order made no measurable difference: SSDSEG_W4_GROUP).
+// Work items are ordered in groups of TWO 32-channel tiles, pixel-tile-major inside a group, and dealt to the XCDs in contiguous
+// runs: an XCD keeps two slices of U (2 x 1.4 MB at 304 reduction channels) in its L2 and the two channel tiles of a pixel tile are
+// taken by two of its CUs back to back, so the second one's input strips are L2 hits (channel-tile-major, one slice per XCD: every
+// XCD streamed the whole input -- 7.8 GB of HBM traffic per launch instead of 5.0, 4 % slower; profiles/r03_w4_group_ab.txt).
 // Epilogue: the 36 x 32 x 32 accumulators go through LDS once; thread = (channel, 4 tiles) gathers the 36 values, applies
 // A^T . A in registers and writes 4 x 4 pixels (+ forward: BatchNorm partial sums, one row per pixel tile, fixed order, no atomics).
 //
@@ -124,7 +126,7 @@ __global__ void __launch_bounds__(W4_THREADS, 1) conv3_wino4_kernel(Wino4Args p)
     const int wave = t >> 6, lane = t & 63, li = lane & 31, hh = lane >> 5;
 
     // PERSISTENT blocks, one per CU: a block walks its share of the work items (pixel tile x 32-channel tile), and the first loads
-    // of the next item are in flight while the current one leaves through its epilogue.  Work order: channel-tile-major, one
+    // of the next item are in flight while the current one leaves through its epilogue.  Work order: see `setup` below; one
     // contiguous run per XCD (blocks go to the XCDs round-robin), the blocks of an XCD interleaved within its run.
     const int mtiles = p.n * p.tiles_h * p.tiles_w;
     const int total = mtiles * p.ntiles_n;
