@@ -438,6 +438,11 @@ int ssdseg_channel_gather(ssdseg_ctx* ctx, const ssdseg_view* in, int ldi, float
 /* rows x cols block copy between row-major matrices of different leading dimension: parameters between their exact Keras
  * shapes (flat bucket) and the zero-padded shapes of those units */
 int ssdseg_copy2d(ssdseg_ctx* ctx, float* dst, int ldd, const float* src, int lds, int rows, int cols);
+/* The same for a table of blocks in ONE launch.  `table` (device): ncopies rows of six 64-bit words {dst pointer, ldd, src pointer,
+ * lds, rows, cols}; max_elems = the largest rows * cols of the table (sizes the grid), total_floats = their sum (timing registry).
+ * ShuffleNetV2 '1x' / '2x' (reference models.py:557-603: stage-2 branches of 58 / 122 channels) keep zero-padded copies of ~50
+ * weight tensors: refreshing them and folding their gradients back was 160 launches of ~6 us per step. */
+int ssdseg_copy2d_batch(ssdseg_ctx* ctx, const long long* table, int ncopies, int max_elems, long long total_floats);
 /* g *= act'(x) in place: backward of a ReLU that follows an Add (ShuffleNetV2 basic unit, models.py:593-595) */
 int ssdseg_act_bwd(ssdseg_ctx* ctx, float* g, int ldg, const float* x, int ldx, int m, int c, int act);
 

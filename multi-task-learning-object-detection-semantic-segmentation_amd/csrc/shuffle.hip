@@ -222,6 +222,20 @@ __global__ void copy2d_kernel(float* __restrict__ dst, int ldd, const float* __r
     }
 }
 
+// the same for a whole table of blocks in ONE launch: blockIdx.y = table row {dst, ldd, src, lds, rows, cols} (six 64-bit words),
+// blockIdx.x strides over its elements
+__global__ void __launch_bounds__(256) copy2d_batch_kernel(const long long* __restrict__ table) {
+    const long long* e = table + 6 * (long long)blockIdx.y;
+    float* __restrict__ dst = reinterpret_cast<float*>(e[0]);
+    const float* __restrict__ src = reinterpret_cast<const float*>(e[2]);
+    const int ldd = (int)e[1], lds = (int)e[3], rows = (int)e[4], cols = (int)e[5];
+    const int total = rows * cols;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int r = i / cols, c = i - r * cols;
+        dst[(long long)r * ldd + c] = src[(long long)r * lds + c];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -326,6 +340,17 @@ int ssdseg_copy2d(ssdseg_ctx* ctx, float* dst, int ldd, const float* src, int ld
     SSDSEG_ARG(src != nullptr, 4);
     SSDSEG_ARG(rows > 0 && cols > 0 && ldd >= cols && lds >= cols, 6);
     SSDSEG_LAUNCH(ctx, 8.0 * rows * cols, 0.0, copy2d_kernel, dim3(ew_blocks((long long)rows * cols)), dim3(256), 0, dst, ldd, src, lds, rows, cols);
+    SSDSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+int ssdseg_copy2d_batch(ssdseg_ctx* ctx, const long long* table, int ncopies, int max_elems, long long total_floats) {
+    SSDSEG_ARG(ctx != nullptr, 1);
+    SSDSEG_ARG(table != nullptr, 2);
+    SSDSEG_ARG(ncopies > 0, 3);
+    SSDSEG_ARG(max_elems > 0, 4);
+    const int gx = (max_elems + 255) / 256 < 16 ? (max_elems + 255) / 256 : 16;
+    SSDSEG_LAUNCH(ctx, 8.0 * (double)total_floats, 0.0, copy2d_batch_kernel, dim3(gx, ncopies, 1), dim3(256), 0, table);
     SSDSEG_LAUNCH_CHECK();
     return 0;
 }

@@ -825,14 +825,33 @@ class Engine:
         return self._bucket_view(layer, wname, grads=True).download()
 
     def _sync_padded(self, kind: str, to_bucket: bool, which: Optional[str] = None):
-        for (lid, wname, k), r in self.__dict__.get("_padded", {}).items():
-            if k != kind or (which is not None and r["which"] != which):
-                continue
-            bv = self._bucket_view(r["layer"], wname, grads=(kind == "g"))
-            if to_bucket:
-                self.ctx.call("ssdseg_copy2d", bv, r["lds"], r["buf"], r["ldd"], r["rows"], r["cols"])
-            else:
-                self.ctx.call("ssdseg_copy2d", r["buf"], r["ldd"], bv, r["lds"], r["rows"], r["cols"])
+        """zero-padded copies of odd-width weights <-> their Keras-shaped slots of the flat bucket: ONE table-driven launch per call
+        (ssdseg_copy2d_batch; the table is built once per (kind, direction, which) -- the pointers never change).  Was one
+        ssdseg_copy2d per tensor: 160 launches per ShuffleNetV2-1x step (SSDSEG_COPY2D_BATCH=0 keeps that, bit-identical)."""
+        padded = self.__dict__.get("_padded", {})
+        if not padded:
+            return
+        key = (kind, to_bucket, which, len(padded))            # (a table made before the last padded tensor was registered is not reused)
+        cache = self.__dict__.setdefault("_padded_tables", {})
+        if key not in cache:
+            rows = []
+            for (lid, wname, k), r in padded.items():
+                if k != kind or (which is not None and r["which"] != which):
+                    continue
+                bv = self._bucket_view(r["layer"], wname, grads=(kind == "g"))
+                if to_bucket:
+                    rows.append((bv.ptr, r["lds"], r["buf"].ptr, r["ldd"], r["rows"], r["cols"]))
+                else:
+                    rows.append((r["buf"].ptr, r["ldd"], bv.ptr, r["lds"], r["rows"], r["cols"]))
+            cache[key] = (rows, self.ctx.array(np.asarray(rows, dtype=np.int64)) if rows else None)
+        rows, table = cache[key]
+        if not rows:
+            return
+        if os.environ.get("SSDSEG_COPY2D_BATCH", "1") == "0":
+            for dst, ldd, src, lds, nr, nc in rows:
+                self.ctx.call("ssdseg_copy2d", C.c_void_p(dst), ldd, C.c_void_p(src), lds, nr, nc)
+            return
+        self.ctx.call("ssdseg_copy2d_batch", table, len(rows), max(nr * nc for *_, nr, nc in rows), sum(nr * nc for *_, nr, nc in rows))
 
     def _pull_layer(self, layer):
         self.ctx.sync()

@@ -127,6 +127,7 @@ _SIGNATURES = {
     "ssdseg_act_bwd": [_vp, _vp, _i, _vp, _i, _i, _i, _i],
     "ssdseg_channel_gather": [_vp, _VP, _i, _vp, _i, C.c_longlong, _i, _vp, _i],
     "ssdseg_copy2d": [_vp, _vp, _i, _vp, _i, _i, _i],
+    "ssdseg_copy2d_batch": [_vp, _vp, _i, _i, C.c_longlong],
     "ssdseg_metric_mask_iou": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, C.POINTER(_f), _vp],
     "ssdseg_metric_label_accuracy": [_vp, _vp, _vp, _i, _i, _i, C.POINTER(_f), _vp],
     "ssdseg_metric_box_iou": [_vp, _vp, _vp, _vp, C.POINTER(_f), _i, _i, _vp],
