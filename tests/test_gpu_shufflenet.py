@@ -95,3 +95,23 @@ def test_shufflenet_full_model_quirk_q1(ctx, rng, size):
     y_mask = np.eye(4, dtype=np.float32)[rng.integers(0, 4, (2, 96, 128))]
     logs = model.train_on_batch(x, {'output-mask': y_mask, 'output-labels': y_labels, 'output-boxes': y_boxes})
     assert np.isfinite(logs['loss']) and abs(logs['output-mask_loss'] - (-np.log(0.25) * (y_mask * np.array([0.05, 0.575, 0.135, 0.24])).sum((1, 2, 3))).mean()) < 1e-2
+
+
+def test_copy2d_and_copy2d_batch_exact(ctx, rng):
+    """ssdseg_copy2d / ssdseg_copy2d_batch (the packed <-> zero-padded weight copies of the odd-width ShuffleNetV2 units, reference
+    models.py:557-603): a table of blocks with different shapes and leading dimensions in one launch == the copies one by one,
+    bit for bit, and nothing outside the blocks is touched"""
+    shapes = [(58, 58, 60, 58), (1, 58, 60, 58), (9, 58, 60, 58), (122, 122, 124, 122), (3, 7, 16, 9)]     # rows, cols, ldd, lds
+    srcs = [rng.normal(0, 1, (r, lds)).astype(np.float32) for r, c, ldd, lds in shapes]
+    d_src = [ctx.array(s) for s in srcs]
+    sentinel = np.float32(-7.5)
+    d_one = [ctx.array(np.full((r, ldd), sentinel, np.float32)) for r, c, ldd, lds in shapes]
+    d_bat = [ctx.array(np.full((r, ldd), sentinel, np.float32)) for r, c, ldd, lds in shapes]
+    for (r, c, ldd, lds), s, d in zip(shapes, d_src, d_one):
+        ctx.call("ssdseg_copy2d", d, ldd, s, lds, r, c)
+    table = ctx.array(np.asarray([(d.ptr, ldd, s.ptr, lds, r, c) for (r, c, ldd, lds), s, d in zip(shapes, d_src, d_bat)], dtype=np.int64))
+    ctx.call("ssdseg_copy2d_batch", table, len(shapes), max(r * c for r, c, _, _ in shapes), sum(r * c for r, c, _, _ in shapes))
+    for (r, c, ldd, lds), s, a, b in zip(shapes, srcs, d_one, d_bat):
+        want = np.full((r, ldd), sentinel, np.float32)
+        want[:, :c] = s[:, :c]
+        assert np.array_equal(a.download(), want) and np.array_equal(b.download(), want)
