@@ -2103,6 +2103,13 @@ int ssdseg_pwconv_bwd_weight(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, co
 // Rescaling + Conv2D 3x3 stride 2 SAME on the 3-channel image (reference models.py:187,196 -> :65; ShuffleNetV2 :622,628)
 // as implicit GEMM [n*ho*wo, 27] x [27, cout] through the same MFMA kernels: the im2col gather happens in the LDS
 // loader, the output leaves the accumulators as full 128-byte row segments, BN statistics come from the epilogue.
+// stem.hip: the direct streaming kernel for <= 64 output channels (SSDSEG_STEM_DIRECT=0: the implicit GEMM below)
+bool ssdseg_stem_direct_takes(int cout);
+bool ssdseg_stem_direct_eligible(int cout);
+int ssdseg_stem_direct_blocks(int n, int h);
+int ssdseg_stem_direct_fwd(ssdseg_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int n, int h, int wdt, int cout,
+                           float in_scale, float in_offset, float* stats);
+
 static void stem_geometry(int h, int wdt, int* ho, int* wo, int* pt, int* pl) {
     same_pad(h, 3, 2, 1, ho, pt);
     same_pad(wdt, 3, 2, 1, wo, pl);
@@ -2114,7 +2121,9 @@ int ssdseg_stem_conv_parts(int n, int h, int w, int cout, int* nparts_host) {
     SSDSEG_ARG(nparts_host != nullptr, 5);
     int ho, wo, pt, pl;
     stem_geometry(h, w, &ho, &wo, &pt, &pl);
-    *nparts_host = rowA_grid_y(n * ho * wo, cout);
+    // (sized for whichever forward kernel may run: the direct one writes one row per block, the implicit GEMM one per grid row)
+    const int a = rowA_grid_y(n * ho * wo, cout), b = ssdseg_stem_direct_eligible(cout) ? ssdseg_stem_direct_blocks(n, h) : 0;
+    *nparts_host = a > b ? a : b;
     return 0;
 }
 
@@ -2128,6 +2137,16 @@ int ssdseg_stem_conv_fwd(ssdseg_ctx* ctx, const float* x, const float* w, const 
     SSDSEG_ARG(n > 0 && h > 0 && wdt > 0, 6);
     SSDSEG_ARG(cin == 3, 9);
     SSDSEG_ARG(cout > 0 && cout % 4 == 0, 10);
+    const bool direct = ssdseg_stem_direct_takes(cout) && (long long)n * h * wdt * 12 < (1LL << 31);      // (32-bit buffer offsets into the image)
+    if (stats != nullptr) {      // the table is sized for the larger of the two kernels' row counts: the rows this launch does not write are zero
+        int nparts = 0, ho_, wo_, pt_, pl_;
+        int rc = ssdseg_stem_conv_parts(n, h, wdt, cout, &nparts);
+        if (rc) return rc;
+        stem_geometry(h, wdt, &ho_, &wo_, &pt_, &pl_);
+        const int mine = direct ? ssdseg_stem_direct_blocks(n, h) : rowA_grid_y(n * ho_ * wo_, cout);
+        if (nparts > mine) SSDSEG_HIP(hipMemsetAsync(stats + (size_t)mine * 2 * cout, 0, (size_t)(nparts - mine) * 2 * cout * sizeof(float), ctx->stream));
+    }
+    if (direct) return ssdseg_stem_direct_fwd(ctx, x, w, bias, y, n, h, wdt, cout, in_scale, in_offset, stats);
     RowAArgs a{};
     a.a0 = x; a.act = SSDSEG_ACT_NONE;
     a.b = w; a.ldb = cout;

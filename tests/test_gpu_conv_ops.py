@@ -321,9 +321,11 @@ def test_bn_finalize_apply_bwd(ctx, rng, m, c, parts):
     assert np.abs(dy - dy_ref).max() < 1e-4 * max(1.0, np.abs(dy_ref).max())
 
 
-@pytest.mark.parametrize("n,h,w,cout,bias", [(2, 48, 64, 32, False), (1, 15, 21, 24, True), (3, 480, 640, 32, False)])
-def test_stem_conv(ctx, rng, n, h, w, cout, bias):
+@pytest.mark.parametrize("form", ["direct", "gemm"])      # csrc/stem.hip (default for <= 64 output channels) / the implicit GEMM of csrc/gemm.hip
+@pytest.mark.parametrize("n,h,w,cout,bias", [(2, 48, 64, 32, False), (1, 15, 21, 24, True), (3, 480, 640, 32, False), (2, 33, 47, 40, False)])
+def test_stem_conv(ctx, rng, monkeypatch, n, h, w, cout, bias, form):
     from ssdseglib import _hip as H
+    monkeypatch.setenv("SSDSEG_STEM_DIRECT", "1" if form == "direct" else "0")
     x = rng.integers(0, 256, (n, h, w, 3)).astype(np.float32)
     wgt = rng.normal(0, 0.3, (3, 3, 3, cout)).astype(np.float32)
     b = rng.normal(0, 0.3, cout).astype(np.float32) if bias else None
