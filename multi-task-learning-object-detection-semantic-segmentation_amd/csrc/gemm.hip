@@ -2103,6 +2103,11 @@ int ssdseg_pwconv_bwd_weight(ssdseg_ctx* ctx, const ssdseg_view* in, int ldx, co
 // Rescaling + Conv2D 3x3 stride 2 SAME on the 3-channel image (reference models.py:187,196 -> :65; ShuffleNetV2 :622,628)
 // as implicit GEMM [n*ho*wo, 27] x [27, cout] through the same MFMA kernels: the im2col gather happens in the LDS
 // loader, the output leaves the accumulators as full 128-byte row segments, BN statistics come from the epilogue.
+// conv3n.hip: the narrow 3x3 conv's input gradient + fused BatchNorm sums as a streaming kernel (cin == 256, cout == 4)
+bool ssdseg_conv3n_direct_takes(int cin, int cout, int ldx);
+int ssdseg_conv3n_bwd_bn_direct(ssdseg_ctx* ctx, const ssdseg_view* in, const ssdseg_gview* dy, const float* w, float* dx, int ldx, int n, int h,
+                                int wdt, const float* in_mean, const float* in_invstd, float* in_dgamma, float* in_dbeta, float* in_k1,
+                                float* in_k0);
 // stem.hip: the direct streaming kernel for <= 64 output channels (SSDSEG_STEM_DIRECT=0: the implicit GEMM below)
 bool ssdseg_stem_direct_takes(int cout);
 bool ssdseg_stem_direct_eligible(int cout);
@@ -2353,6 +2358,8 @@ int ssdseg_conv3x3_bwd_data_bn(ssdseg_ctx* ctx, const ssdseg_view* in, const ssd
     SSDSEG_ARG(in_mean != nullptr && in_invstd != nullptr, 12);
     SSDSEG_ARG(in_k1 != nullptr && in_k0 != nullptr, 16);
     const long long m = (long long)n * h * wdt;
+    if (conv3_narrow(cin, cout) && ssdseg_conv3n_direct_takes(cin, cout, ldx) && m < (1LL << 29))      // conv3n.hip: the streaming form (256 -> 4)
+        return ssdseg_conv3n_bwd_bn_direct(ctx, in, dy, w, dx, ldx, n, h, wdt, in_mean, in_invstd, in_dgamma, in_dbeta, in_k1, in_k0);
     if (conv3_narrow(cin, cout)) {
         // tap-expanded form: dz[m][tap][o] = dy[m - d(tap)][o], then dx = dz * W2^T is a pointwise GEMM whose float4 epilogue holds the dx
         // tile and reads the matching tile of the raw input -- that BN's sums ride there (the 256 -> 4 logits conv of the decoder:

@@ -110,6 +110,16 @@ def test_conv3x3_fwd_bwd(ctx, rng, monkeypatch, n, h, w, cin, cout, family):
     k0_ref = sc.astype(np.float64) * (dgamma * invstd * mean - dbeta) / cnt
     assert np.abs(outs[2].download() - k1_ref).max() < 1e-4 * max(np.abs(k1_ref).max(), 1e-9)
     assert np.abs(outs[3].download() - k0_ref).max() < 1e-4 * max(np.abs(k0_ref).max(), 1e-9)
+    if family == "narrow" and cin == 256 and cout == 4:
+        # that was the streaming kernel of csrc/conv3n.hip (default for 256 -> 4); the tap-expanded GEMM form of the same entry point:
+        monkeypatch.setenv("SSDSEG_CONV3N_DIRECT", "0")
+        outs2 = [ctx.empty(cin) for _ in range(4)]
+        ddx.upload(base)
+        ctx.call("ssdseg_conv3x3_bwd_data_bn", H.view(dx_, dsc, dsh, act), H.gview(*bufs, act=O.ACT_RELU6), dw_, ddx, cin, n, h, w, cin, cout,
+                 ctx.array(mean), ctx.array(invstd), *outs2)
+        assert rel_err(ddx.download(), dx_ref) < ctol
+        assert np.abs(outs2[0].download() - dgamma).max() < tol and np.abs(outs2[1].download() - dbeta).max() < tol
+        monkeypatch.delenv("SSDSEG_CONV3N_DIRECT")
     # the engine's form: the BatchNorm gradient view materialised once, then the identity view (the halo-tile kernel's input),
     # written into a channel slice of a wider (concat) gradient buffer, overwrite and accumulate
     dmat = ctx.array(dy)
