@@ -287,5 +287,8 @@ inline size_t wres_lds_bytes(int r, int wn) {
     const int rp = cdiv(r, BK) * BK;
     const size_t stage = (size_t)4 * 32 * AS;                        // also >= the 12 KiB / 8*BN floats the tails need
     const size_t bytes = ((size_t)rp * (32 * wn + 1) + 4 * (size_t)rp + stage) * sizeof(float);
-    return bytes <= 52 * 1024 ? bytes : 0;                           // three blocks per CU
+    // 64 KiB: two blocks per CU.  (52 KiB -- three blocks -- until round 3: the decoder's 144 -> 48 backbone conv needs 62.6 KiB and ran
+    // as the row-tile GEMM at 190 us; resident: 149 us.  No layer of the models sits between 52 and 64 KiB otherwise.)  SSDSEG_WRES_LDS_KB: A/B runs
+    static const size_t cap = getenv("SSDSEG_WRES_LDS_KB") != nullptr ? (size_t)atoi(getenv("SSDSEG_WRES_LDS_KB")) * 1024 : (size_t)64 * 1024;
+    return bytes <= cap ? bytes : 0;
 }
