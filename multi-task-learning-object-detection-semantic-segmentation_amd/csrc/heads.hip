@@ -542,14 +542,22 @@ __global__ void __launch_bounds__(TL * TL) mask_head_bwd_tile_kernel(const float
     int ox0 = (ix == 0) ? 0 : (ix * F - F / 2 - F), ox1 = (ix == w - 1) ? wo - 1 : (ix * F + F + F / 2 + 1);
     oy0 = oy0 < 0 ? 0 : oy0; ox0 = ox0 < 0 ? 0 : ox0;
     oy1 = oy1 > ho - 1 ? ho - 1 : oy1; ox1 = ox1 > wo - 1 ? wo - 1 : ox1;
+    // the column weights of the window once per thread, not once per (row, column) -- the same lerp_weight values, the same products and
+    // the same summation order (rows, then columns, zero weights skipped): bit-identical, ~130 weight evaluations per thread less
+    constexpr int WMAX = 3 * F + 2;                   // candidate columns of a window: [i*F - F/2 - F, i*F + F + F/2 + 1]
+    float wxs[WMAX];
+#pragma unroll
+    for (int k = 0; k < WMAX; ++k) wxs[k] = (ox0 + k <= ox1) ? lerp_weight(ox0 + k, ix, w, inv) : 0.f;
     float4 acc = f4(0.f);
     for (int oy = oy0; oy <= oy1; ++oy) {
         const float wy = lerp_weight(oy, iy, h, inv);
         if (wy == 0.f) continue;
-        for (int ox = ox0; ox <= ox1; ++ox) {
-            const float wx = lerp_weight(ox, ix, w, inv);
+        const float4* drow = dz + (oy - oyb) * R + (ox0 - oxb);
+#pragma unroll
+        for (int k = 0; k < WMAX; ++k) {
+            const float wx = wxs[k];
             if (wx == 0.f) continue;
-            const float4 d = dz[(oy - oyb) * R + (ox - oxb)];
+            const float4 d = drow[k];
             const float wgt = wy * wx * loss_scale;
             acc.x = fmaf(wgt, d.x, acc.x);
             acc.y = fmaf(wgt, d.y, acc.y);
