@@ -322,7 +322,8 @@ def test_bn_finalize_apply_bwd(ctx, rng, m, c, parts):
 
 
 @pytest.mark.parametrize("form", ["direct", "gemm"])      # csrc/stem.hip (default for <= 64 output channels) / the implicit GEMM of csrc/gemm.hip
-@pytest.mark.parametrize("n,h,w,cout,bias", [(2, 48, 64, 32, False), (1, 15, 21, 24, True), (3, 480, 640, 32, False), (2, 33, 47, 40, False)])
+@pytest.mark.parametrize("n,h,w,cout,bias", [(2, 48, 64, 32, False), (1, 15, 21, 24, True), (3, 480, 640, 32, False), (2, 33, 47, 40, False),
+                                             (9, 480, 64, 32, False)])      # 2,160 output rows: more than the direct kernel's 2,048 blocks
 def test_stem_conv(ctx, rng, monkeypatch, n, h, w, cout, bias, form):
     from ssdseglib import _hip as H
     monkeypatch.setenv("SSDSEG_STEM_DIRECT", "1" if form == "direct" else "0")

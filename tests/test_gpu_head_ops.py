@@ -39,6 +39,7 @@ def gview_inputs(rng, shape, act):
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout", [(2, 9, 11, 16, 32), (1, 12, 16, 304, 256), (2, 8, 8, 256, 4), (1, 5, 5, 24, 8), (1, 1, 1, 8, 8),
+                                            (18, 120, 22, 256, 4),  # 2,160 image rows: the streaming logits-conv gradient (conv3n.hip) walks > 2,048 rows per launch, 22 = five 4-pixel trips + 2
                                             (3, 14, 40, 72, 96),    # 40 = one full + one partial 32-pixel step / tile per image row
                                             (2, 17, 33, 40, 200),   # odd number of 8-channel steps; two 100-column tiles of a 128-wide block
                                             (1, 8, 32, 12, 16),     # cin not a multiple of 8: the implicit-GEMM forward, halo-tile backward
