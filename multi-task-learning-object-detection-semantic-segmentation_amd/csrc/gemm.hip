@@ -1630,6 +1630,8 @@ int conv3_wino4_launch(ssdseg_ctx* ctx, const Conv3TArgs& a, const float* w, int
         const long long ob = (((long long)a.n * a.h * a.w - 1) * a.ldo + a.nout) * 4;
         p.out_bytes = ob < (1LL << 31) ? (unsigned)ob : 0u;
         if (ob >= (1LL << 31) && !p.accumulate) p.accumulate = 2;      // 32-bit buffer offsets do not reach: plain stores
+        const char* fe = getenv("SSDSEG_W4_PLAIN_STORES");              // (parity tests) that path at any size
+        if (fe != nullptr && fe[0] == '1' && !p.accumulate) p.accumulate = 2;
     }
     p.trace = nullptr;
     const size_t lds = wino4_lds_floats(a.cred) * sizeof(float);

@@ -38,6 +38,35 @@ def gview_inputs(rng, shape, act):
     return (g, y, scale, shift, k1, k0), dy.astype(np.float32)
 
 
+def test_conv3x3_wino4_plain_store_path(ctx, rng, monkeypatch):
+    """Outputs of 2 GiB and more leave the F(4x4, 3x3) kernel through 64-bit addresses instead of range-checked buffer stores
+    (conv3_wino4.h, `accumulate == 2`); SSDSEG_W4_PLAIN_STORES=1 takes that path at a size the oracle finishes in seconds."""
+    from ssdseglib import _hip as H
+    monkeypatch.setenv("SSDSEG_CONV3_NARROW", "0")
+    monkeypatch.setenv("SSDSEG_CONV3_TILE", "1")
+    monkeypatch.setenv("SSDSEG_CONV3_WINOGRAD", "1")
+    monkeypatch.setenv("SSDSEG_CONV3_F4", "1")
+    monkeypatch.setenv("SSDSEG_W4_PLAIN_STORES", "1")
+    n, h, w, cin, cout = 2, 13, 18, 48, 80          # partial tiles on both edges, a partial 32-channel tile either way (reductions of 48 / 80: whole 16-channel steps)
+    act = O.ACT_RELU6
+    x, sc, sh, a = view_inputs(rng, (n, h, w, cin), act)
+    wgt = (rng.normal(0, 1, (3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+    y_ref = O.conv2d_fwd(a.astype(np.float64), wgt.astype(np.float64))
+    dx_, dsc, dsh, dw_ = ctx.array(x), ctx.array(sc), ctx.array(sh), ctx.array(wgt)
+    y = ctx.empty(y_ref.shape)
+    nparts = ctx.parts("ssdseg_conv3x3_parts", n, h, w, cin, cout)
+    stats = ctx.empty((nparts, 2, cout))
+    ctx.call("ssdseg_conv3x3_fwd", H.view(dx_, dsc, dsh, act), cin, dw_, y, n, h, w, cin, cout, stats)
+    assert rel_err(y.download(), y_ref) < 5e-5
+    st = stats.download().astype(np.float64).sum(axis=0)
+    assert rel_err(st[1], (y_ref ** 2).sum(axis=(0, 1, 2))) < 1e-4
+    dy = rng.normal(0, 1, y_ref.shape).astype(np.float32)
+    dx_ref, _, _ = O.conv2d_bwd(a.astype(np.float64), wgt.astype(np.float64), dy.astype(np.float64))
+    ddx = ctx.empty(x.shape)
+    ctx.call("ssdseg_conv3x3_bwd_data", H.gview(ctx.array(dy)), dw_, ddx, cin, n, h, w, cin, cout, 0)
+    assert rel_err(ddx.download(), dx_ref) < 5e-5
+
+
 @pytest.mark.parametrize("n,h,w,cin,cout", [(2, 9, 11, 16, 32), (1, 12, 16, 304, 256), (2, 8, 8, 256, 4), (1, 5, 5, 24, 8), (1, 1, 1, 8, 8),
                                             (18, 120, 22, 256, 4),  # 2,160 image rows: the streaming logits-conv gradient (conv3n.hip) walks > 2,048 rows per launch, 22 = five 4-pixel trips + 2
                                             (3, 14, 40, 72, 96),    # 40 = one full + one partial 32-pixel step / tile per image row
