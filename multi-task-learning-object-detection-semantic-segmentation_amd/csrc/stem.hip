@@ -4,7 +4,7 @@
 // The layer reads 12 bytes and writes 4 * cout bytes per output pixel with 27 multiply-adds per output value: a streaming kernel.  As an
 // implicit GEMM (gemm.hip, LD = 2: K = 27 padded to 32, 128-row tiles, LDS staging, transposing epilogue) it ran 2.2 TB/s of
 // algorithmic traffic at 480 x 640 x 32 (0.27 ms).  Here a thread is (output pixel, four output channels): the cout / 4 lanes of a pixel
-// sit next to each other, so a wave's store is one contiguous run of 64 x 16 bytes, the nine 12-byte input reads of a pixel are the
+// sit next to each other (in whole groups of four lanes, see QP), so a wave's store is one contiguous run of 64 x 16 bytes, the nine 12-byte input reads of a pixel are the
 // same addresses for all its lanes (one request), and the 27 x 4 weights of the thread live in registers for the whole kernel.  The
 // input rescale (x * s + o, zero padding AFTER it) is folded into the weights: sum_valid (x s + o) w = sum_valid x (s w) + sum_valid o w.
 // A block walks whole output rows (no per-pixel division); BatchNorm partial sums: one row per block, fixed order.
@@ -26,12 +26,18 @@ struct StemArgs {
 
 template <int Q>   // channel quads per pixel: cout == 4 * Q
 __global__ void __launch_bounds__(256) stem_fwd_direct_kernel(StemArgs p) {
-    constexpr int PPB = 256 / Q;                      // pixels per block iteration
+    // lanes per pixel: Q rounded up to whole groups of four lanes.  The nine 12-byte reads of a pixel are the same addresses for all its
+    // lanes, and the texture addresser takes one distinct address per aligned group of four lanes and cycle: with 6 lanes per pixel
+    // (24 channels, ShuffleNetV2) every other group straddles two pixels and the kernel ran 243 us against 170 for 32 channels (88 for
+    // 16); with 8 lanes per pixel, two of them idle, it takes the 32-channel time (scripts/dbg/stem_time.py)
+    constexpr int QP = (Q + 3) / 4 * 4;
+    constexpr int PPB = 256 / QP;                     // pixels per block iteration
     __shared__ float red[2][PPB][4 * Q];
     __shared__ float wo_s[9][4 * Q];                  // offset * sum_c w[tap][c][.]: what a tap adds through the rescale's offset
     const int t = threadIdx.x;
-    const int q = t % Q, pix = t / Q;
-    const bool lane_on = pix < PPB;
+    const int pix = t / QP;
+    const bool lane_on = pix < PPB && t % QP < Q;
+    const int q = t % QP < Q ? t % QP : Q - 1;        // (idle lanes compute on the last quad's weights, store nothing)
     // weights of this thread's four channels with the input scale folded in: ws[tap][c] = scale * w
     float4 ws[27];
     float4 wo_all = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -45,7 +51,7 @@ __global__ void __launch_bounds__(256) stem_fwd_direct_kernel(StemArgs p) {
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
         s = make_float4(s.x * p.offset, s.y * p.offset, s.z * p.offset, s.w * p.offset);
-        if (pix == 0) *reinterpret_cast<float4*>(&wo_s[tap][4 * q]) = s;
+        if (pix == 0 && lane_on) *reinterpret_cast<float4*>(&wo_s[tap][4 * q]) = s;
         wo_all.x += s.x; wo_all.y += s.y; wo_all.z += s.z; wo_all.w += s.w;
     }
     __syncthreads();
