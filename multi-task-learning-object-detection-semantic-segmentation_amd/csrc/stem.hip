@@ -27,9 +27,10 @@ struct StemArgs {
 template <int Q>   // channel quads per pixel: cout == 4 * Q
 __global__ void __launch_bounds__(256) stem_fwd_direct_kernel(StemArgs p) {
     // lanes per pixel: Q rounded up to whole groups of four lanes.  The nine 12-byte reads of a pixel are the same addresses for all its
-    // lanes, and the texture addresser takes one distinct address per aligned group of four lanes and cycle: with 6 lanes per pixel
-    // (24 channels, ShuffleNetV2) every other group straddles two pixels and the kernel ran 243 us against 170 for 32 channels (88 for
-    // 16); with 8 lanes per pixel, two of them idle, it takes the 32-channel time (scripts/dbg/stem_time.py)
+    // lanes; with 6 lanes per pixel (24 channels, ShuffleNetV2) every other aligned group of four lanes holds two different addresses and
+    // the kernel ran 243 us against 170 for 32 channels (88 for 16); with 8 lanes per pixel, two of them idle, it takes the 32-channel
+    // time (scripts/dbg/stem_time.py, profiles/r03_stem_lanes_per_pixel.txt -- also what did NOT help: nine wide loads per pixel,
+    // rows staged in LDS, more pixels in flight)
     constexpr int QP = (Q + 3) / 4 * 4;
     constexpr int PPB = 256 / QP;                     // pixels per block iteration
     __shared__ float red[2][PPB][4 * Q];
